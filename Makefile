@@ -1,0 +1,30 @@
+# Builds the gfx950 C-ABI library (flope_amd/lib/libflope_amd.so) and the CPU-only
+# host test harness (tests/host_harness/libflope_host_harness.so).
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+CSRC     := flope_amd/csrc
+OBJDIR   := build/obj
+LIB      := flope_amd/lib/libflope_amd.so
+HARNESS  := tests/host_harness/libflope_host_harness.so
+SRCS     := $(wildcard $(CSRC)/*.hip)
+OBJS     := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+HDRS     := $(wildcard $(CSRC)/*.h) include/flope_amd.h
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wno-unused-value -Iinclude
+
+all: $(LIB) $(HARNESS)
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+$(HARNESS): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack.h
+	g++ -O2 -fPIC -shared -std=c++17 -I$(CSRC) -o $@ $<
+
+clean:
+	rm -rf build $(LIB) $(HARNESS)
+
+.PHONY: all clean

@@ -1,0 +1,147 @@
+// Shared device-side types and launch-parameter structs for the flower-pose
+// hot path (gfx950 only).  Activation tensors live in HBM as zero-bordered
+// NHWC ("padded NHWC"): [B][H+2][W+2][C] with a one-pixel ring of zeros that is
+// written once at flope_create and never touched again, so a 3x3 / pad-1
+// convolution is pure address arithmetic -- no bounds checks in any inner loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<f16_t> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// pack two floats into one 32-bit word of two T (low half = a)
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) {
+  T x = from_f32<T>(a), y = from_f32<T>(b);
+  unsigned short ux = __builtin_bit_cast(unsigned short, x);
+  unsigned short uy = __builtin_bit_cast(unsigned short, y);
+  return (unsigned)ux | ((unsigned)uy << 16);
+}
+template <typename T> __device__ __forceinline__ float unpack_lo(unsigned w) {
+  return to_f32<T>(__builtin_bit_cast(T, (unsigned short)(w & 0xffffu)));
+}
+template <typename T> __device__ __forceinline__ float unpack_hi(unsigned w) {
+  return to_f32<T>(__builtin_bit_cast(T, (unsigned short)(w >> 16)));
+}
+
+// Bijective XCD-aware block remap (blocks b and b+8 share an XCD under the
+// observed round-robin dispatch; speed only, never correctness): each XCD gets a
+// contiguous run of logical tile ids so tiles that share halo rows / weight
+// panels hit the same L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution on MFMA (conv_mfma.hip)
+struct ConvP {
+  const void* in;      // padded NHWC  [B][Hip][Wip][Cin]
+  void* out;           // padded NHWC  [B][Hop][Wop][Cout]
+  const void* res;     // optional residual, same shape as out (nullptr = none)
+  const void* w;       // packed weights [ntile][step][BN rows][64 k] in LDS image order
+  const float* bias;   // [Cout] folded BN shift
+  int B, Hip, Wip, Cin;
+  int Ho, Wo, Hop, Wop, Cout;
+  int stride;          // 1 or 2
+  int ntaps;           // 9 (3x3, pad 1) or 1 (1x1, pad 0: centre tap of the padded window)
+  int M;               // B*Ho*Wo
+  int relu;
+  int nchunks;         // Cin / 64
+  int mtiles, ntiles;
+  int per_image;       // 1: M tiles never straddle two images (tiles_per_image below)
+  int tiles_per_image;
+  int patch_rows_max;  // patch mode: LDS rows reserved
+};
+
+// Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU
+struct StemP {
+  const void* in;      // [B][Hip][Wip][4]   3-pixel zero border (+ right/bottom slack)
+  void* out;           // padded NHWC [B][Ho+2][Wo+2][64]
+  const void* w;       // packed [7 ky][64 rows][32 k] LDS image order
+  const float* bias;   // [64]
+  int B, Hip, Wip;
+  int Ho, Wo;
+  int tiles_per_image;
+  int patch_rows_max;
+};
+
+struct PoolP {         // 3x3 s2 p1 max-pool on padded NHWC
+  const void* in; void* out;
+  int B, Hip, Wip, C, Ho, Wo;
+};
+
+struct NaiveConvP {    // strict fp32 direct convolution on padded NHWC float tensors
+  const float* in; float* out; const float* res; const float* w; const float* bias;
+  int B, Hip, Wip, Cin_stored, Cin, Ho, Wo, Hop, Wop, Cout;
+  int KH, KW, stride, in_off;  // input pixel = (ho*stride + ky + in_off, wo*stride + kx + in_off)
+  int relu;
+};
+
+// ---------------------------------------------------------------------------
+// Shared MFMA epilogue: one lane = one output pixel x (4*NT) consecutive channels.
+// acc + bias (+ residual) (ReLU) -> 16-bit, written as 16-byte NHWC stores into the
+// interior of the zero-bordered output tensor.
+template <typename T, int NT>
+__device__ __forceinline__ void conv_epilogue_px(const ConvP& p, const f32x4 (&acc)[NT], int m, bool valid,
+                                                 int cb, const float (&bias)[NT * 4], int HoWo) {
+  if (!valid) return;
+  const int b = m / HoWo;
+  const int r = m - b * HoWo;
+  const int ho = r / p.Wo;
+  const int wo = r - ho * p.Wo;
+  const size_t pix = ((size_t)b * p.Hop + ho + 1) * p.Wop + wo + 1;
+  const size_t off = (pix * p.Cout + cb) * 2;
+  float v[NT * 4];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[ct][q] + bias[ct * 4 + q];
+  if (p.res) {
+    const char* rp = (const char*)p.res + off;
+#pragma unroll
+    for (int c = 0; c < NT / 2; ++c) {
+      const u32x4 rv = *(const u32x4*)(rp + c * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[c * 8 + q * 2] += unpack_lo<T>(rv[q]);
+        v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[q]);
+      }
+    }
+  }
+  if (p.relu) {
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  char* op = (char*)p.out + off;
+#pragma unroll
+  for (int c = 0; c < NT / 2; ++c) {
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
+    *(u32x4*)(op + c * 16) = o;
+  }
+}
+

@@ -1,0 +1,530 @@
+// C-ABI of the MI355X flower-pose hot path (include/flope_amd.h): engine handle,
+// launch plan, BatchNorm folding + MFMA weight packing, and the forward pass
+//   crop batch -> PoseResNet trunk -> fp32 head -> special Procrustes.
+// Reference behaviour restated: sunflower/models/posenet.py:5-34 (network),
+// sunflower/utils/conversion.py:54-58 (Procrustes), eval-mode semantics throughout
+// (BatchNorm running statistics, dropout = identity).
+#include "../../include/flope_amd.h"
+#include "common.h"
+#include "host_pack.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+// kernels (other translation units)
+extern "C" int flope_conv_mfma_init();
+extern "C" int flope_conv_mfma_launch(const ConvP* p, int dtype, int cfg, int patch, size_t lds, void* stream);
+extern "C" int flope_stem_init();
+extern "C" int flope_stem_launch(const StemP* p, int dtype, size_t lds, void* stream);
+extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream);
+extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, int w, int C, int dtype, void* stream);
+extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* b1, float* hidden, int B, int K, int N, void* stream);
+extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, void* stream);
+extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
+extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
+extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
+
+using namespace flope_host;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+constexpr double kBnEps = 1e-5;
+constexpr size_t kLdsTwoBlocks = 80 * 1024;   // <= this: two workgroups per CU
+constexpr size_t kLdsMax = 160 * 1024;
+
+struct Conv {
+  std::string name, bn;
+  int cin = 0, cout = 0, k = 0, stride = 1;
+  int in_buf = -1, out_buf = -1, res_buf = -1;
+  int hin = 0, win = 0, hout = 0, wout = 0;   // unpadded
+  int relu = 0;
+  // plan
+  int cfg = 0, patch = 0, per_image = 0, tiles_per_image = 0, mtiles = 0, ntiles = 0, rows_max = 0;
+  size_t lds = 0;
+  // device weights
+  void* w_packed = nullptr;    // MFMA image (16-bit)
+  float* w_naive = nullptr;    // [ky][kx][ci][cout]
+  float* bias = nullptr;
+};
+
+struct Buf { void* ptr = nullptr; size_t bytes = 0; int C = 0, h = 0, w = 0; };
+
+}  // namespace
+
+struct flope_engine {
+  int device = 0, H = 0, W = 0, maxB = 0, dtype = 0, bod = 2048;
+  int esz = 2;                       // bytes per trunk element
+  // stem
+  int sHip = 0, sWip = 0, Hs = 0, Ws = 0, stem_tiles = 0, stem_rows = 0;
+  size_t stem_lds = 0;
+  void* stem_in = nullptr; size_t stem_in_bytes = 0;
+  void* stem_w = nullptr; float* stem_w_naive = nullptr; float* stem_bias = nullptr;
+  std::vector<Buf> bufs;             // 0 stem_out, 1 pool, then per block: mid, [ds], out
+  std::vector<Conv> convs;
+  int stage_buf[10];                 // FLOPE_STAGE_* (0..9) -> buffer index
+  int final_buf = -1;
+  float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+  float* r9_scratch = nullptr;
+  bool weights_loaded = false;
+  int opt_patch = 1, opt_bm256 = 1;
+  int last_batch = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(flope_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                   \
+  do {                                                                                     \
+    hipError_t _s = (call);                                                                \
+    if (_s != hipSuccess)                                                                  \
+      return fail(e, FLOPE_EHIP, std::string(#call) + ": " + hipGetErrorString(_s));       \
+  } while (0)
+
+#define K_TRY(e, what, call)                                                               \
+  do {                                                                                     \
+    int _s = (call);                                                                       \
+    if (_s != 0)                                                                           \
+      return fail(e, FLOPE_EHIP, std::string(what) + ": " + hipGetErrorString((hipError_t)_s)); \
+  } while (0)
+
+int out_dim(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+// ---- plan ----------------------------------------------------------------------
+void tile_dims(int cfg, int* BM, int* BN) {
+  *BM = cfg == 2 ? 256 : 128;
+  *BN = cfg == 1 ? 128 : 64;
+}
+
+// exact worst-case number of padded input rows a patch tile needs
+int patch_rows(const Conv& c, int B, int BM, bool per_image) {
+  const int HoWo = c.hout * c.wout, Hip = c.hin + 2;
+  long M = (long)B * HoWo;
+  int worst = 0;
+  auto rows_of = [&](long m0, long mend) {
+    const long ml = mend - 1;
+    const long b0 = m0 / HoWo, ho0 = (m0 - b0 * HoWo) / c.wout;
+    const long b1 = ml / HoWo, ho1 = (ml - b1 * HoWo) / c.wout;
+    return (int)((b1 * Hip + ho1 * c.stride + 2) - (b0 * Hip + ho0 * c.stride) + 1);
+  };
+  if (per_image) {
+    const int tpi = (HoWo + BM - 1) / BM;
+    for (int t = 0; t < tpi; ++t) {
+      const long m0 = (long)t * BM, mend = std::min<long>(m0 + BM, HoWo);
+      worst = std::max(worst, rows_of(m0, mend));
+    }
+  } else {
+    for (long m0 = 0; m0 < M; m0 += BM) worst = std::max(worst, rows_of(m0, std::min<long>(m0 + BM, M)));
+  }
+  return worst;
+}
+
+void plan_conv(flope_engine* e, Conv& c) {
+  const int B = e->maxB;
+  const int HoWo = c.hout * c.wout;
+  const int Wip = c.win + 2;
+  struct Cand { int cfg, patch, per_image, rows; size_t lds; };
+  std::vector<Cand> cands;
+  const bool can_patch = e->opt_patch && c.k == 3 && c.stride == 1;
+  std::vector<int> cfgs;
+  if (c.cout == 64) { if (e->opt_bm256) cfgs.push_back(2); cfgs.push_back(0); }
+  else cfgs.push_back(1);
+  for (int cfg : cfgs) {
+    int BM, BN; tile_dims(cfg, &BM, &BN);
+    if (can_patch) {
+      for (int pi = 0; pi < 2; ++pi) {
+        const int rows = patch_rows(c, B, BM, pi != 0);
+        cands.push_back({cfg, 1, pi, rows, (size_t)2 * BN * 128 + (size_t)rows * Wip * 128});
+      }
+    }
+    cands.push_back({cfg, 0, 0, 0, (size_t)2 * BN * 128 + (size_t)2 * BM * 128});
+  }
+  // first candidate that lets two workgroups share a CU; else the smallest that fits at all
+  const Cand* pick = nullptr;
+  for (const Cand& cd : cands)
+    if (cd.lds <= kLdsTwoBlocks) { pick = &cd; break; }
+  if (!pick)
+    for (const Cand& cd : cands)
+      if (cd.lds <= kLdsMax && (!pick || cd.lds < pick->lds)) pick = &cd;
+  int BM, BN; tile_dims(pick->cfg, &BM, &BN);
+  c.cfg = pick->cfg; c.patch = pick->patch; c.per_image = pick->per_image; c.rows_max = pick->rows; c.lds = pick->lds;
+  c.tiles_per_image = (HoWo + BM - 1) / BM;
+  c.ntiles = c.cout / BN;
+  (void)B;
+}
+
+void conv_params(const flope_engine* e, const Conv& c, int batch, ConvP* p) {
+  int BM, BN; tile_dims(c.cfg, &BM, &BN);
+  memset(p, 0, sizeof(*p));
+  p->in = e->bufs[c.in_buf].ptr; p->out = e->bufs[c.out_buf].ptr;
+  p->res = c.res_buf >= 0 ? e->bufs[c.res_buf].ptr : nullptr;
+  p->w = c.w_packed; p->bias = c.bias;
+  p->B = batch; p->Hip = c.hin + 2; p->Wip = c.win + 2; p->Cin = c.cin;
+  p->Ho = c.hout; p->Wo = c.wout; p->Hop = c.hout + 2; p->Wop = c.wout + 2; p->Cout = c.cout;
+  p->stride = c.stride; p->ntaps = c.k == 3 ? 9 : 1;
+  p->M = batch * c.hout * c.wout; p->relu = c.relu; p->nchunks = c.cin / 64;
+  p->per_image = c.per_image; p->tiles_per_image = c.tiles_per_image;
+  p->mtiles = c.per_image ? batch * c.tiles_per_image : (p->M + BM - 1) / BM;
+  p->ntiles = c.ntiles; p->patch_rows_max = c.rows_max;
+}
+
+template <typename V>
+int upload(flope_engine* e, const std::vector<V>& host, void** dev) {
+  if (*dev) { hipFree(*dev); *dev = nullptr; }
+  HIP_TRY(e, hipMalloc(dev, host.size() * sizeof(V)));
+  HIP_TRY(e, hipMemcpy(*dev, host.data(), host.size() * sizeof(V), hipMemcpyHostToDevice));
+  return 0;
+}
+
+struct Tensors {
+  std::map<std::string, std::pair<const float*, std::vector<int64_t>>> t;
+  const float* get(flope_engine* e, const std::string& name, const std::vector<int64_t>& shape, int* rc) const {
+    auto it = t.find(name);
+    if (it == t.end()) { *rc = fail(e, FLOPE_EWEIGHTS, "state_dict entry missing: " + name); return nullptr; }
+    if (it->second.second != shape) {
+      std::string got, want;
+      for (auto d : it->second.second) got += std::to_string(d) + ",";
+      for (auto d : shape) want += std::to_string(d) + ",";
+      *rc = fail(e, FLOPE_EWEIGHTS, "size mismatch for " + name + ": got [" + got + "] expected [" + want + "]");
+      return nullptr;
+    }
+    return it->second.first;
+  }
+};
+
+// fold eval-mode BN into a bias-free conv: w' = w * g / sqrt(v + eps), b' = beta - mean * g / sqrt(v + eps)
+int fold(flope_engine* e, const Tensors& ts, const std::string& conv, const std::string& bn, int cout, int cin,
+         int k, std::vector<float>* wf, std::vector<float>* bf) {
+  int rc = 0;
+  const float* w = ts.get(e, conv + ".weight", {cout, cin, k, k}, &rc); if (!w) return rc;
+  const float* g = ts.get(e, bn + ".weight", {cout}, &rc); if (!g) return rc;
+  const float* b = ts.get(e, bn + ".bias", {cout}, &rc); if (!b) return rc;
+  const float* m = ts.get(e, bn + ".running_mean", {cout}, &rc); if (!m) return rc;
+  const float* v = ts.get(e, bn + ".running_var", {cout}, &rc); if (!v) return rc;
+  const size_t per = (size_t)cin * k * k;
+  wf->resize((size_t)cout * per); bf->resize(cout);
+  double wmax = 0.0;
+  for (int co = 0; co < cout; ++co) {
+    const double scale = (double)g[co] / sqrt((double)v[co] + kBnEps);
+    (*bf)[co] = (float)((double)b[co] - (double)m[co] * scale);
+    for (size_t i = 0; i < per; ++i) {
+      const double x = (double)w[co * per + i] * scale;
+      (*wf)[co * per + i] = (float)x;
+      if (!(fabs(x) <= 3.0e38)) return fail(e, FLOPE_EWEIGHTS, "non-finite folded weight in " + conv);
+      wmax = std::max(wmax, fabs(x));
+    }
+    if (!std::isfinite((*bf)[co])) return fail(e, FLOPE_EWEIGHTS, "non-finite folded bias in " + bn);
+  }
+  if (e->dtype == FLOPE_DT_F16 && wmax > 6.0e4)
+    return fail(e, FLOPE_EWEIGHTS, "folded weights of " + conv + " exceed the float16 range; use bf16 or f32");
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================
+extern "C" const char* flope_version(void) { return "flope_amd 0.1 (gfx950; mfma_f32_16x16x32 bf16/f16; fp32 head)"; }
+
+extern "C" const char* flope_last_error(flope_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+static int rebuild_plan(flope_engine* e) {
+  for (Conv& c : e->convs) plan_conv(e, c);
+  return 0;
+}
+
+extern "C" int flope_create(int device_id, int height, int width, int max_batch, int dtype, int backbone_out_dim,
+                            flope_handle* out) {
+  if (!out) return fail(nullptr, FLOPE_EINVAL, "flope_create: out is NULL");
+  *out = nullptr;
+  if (height < 32 || width < 32 || height > 4096 || width > 4096)
+    return fail(nullptr, FLOPE_EINVAL, "flope_create: crop size must be within 32..4096");
+  if (max_batch < 1) return fail(nullptr, FLOPE_EINVAL, "flope_create: max_batch must be >= 1");
+  if (dtype < 0 || dtype > 2) return fail(nullptr, FLOPE_EINVAL, "flope_create: unknown dtype");
+  if (backbone_out_dim < 1) return fail(nullptr, FLOPE_EINVAL, "flope_create: backbone_out_dim must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, FLOPE_EHIP, "flope_create: no HIP device visible (the product path has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, FLOPE_EINVAL, "flope_create: bad device id");
+  flope_engine* e = new flope_engine();
+  e->device = device_id; e->H = height; e->W = width; e->maxB = max_batch; e->dtype = dtype; e->bod = backbone_out_dim;
+  e->esz = dtype == FLOPE_DT_F32 ? 4 : 2;
+#define CREATE_TRY(call)                                                                         \
+  do {                                                                                           \
+    hipError_t _s = (call);                                                                      \
+    if (_s != hipSuccess) {                                                                      \
+      int _rc = fail(nullptr, FLOPE_EHIP, std::string(#call) + ": " + hipGetErrorString(_s));    \
+      flope_destroy(e);                                                                          \
+      return _rc;                                                                                \
+    }                                                                                            \
+  } while (0)
+  CREATE_TRY(hipSetDevice(device_id));
+  if (dtype != FLOPE_DT_F32) {
+    int s = flope_conv_mfma_init();
+    if (s == 0) s = flope_stem_init();
+    if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
+  }
+  const size_t B = (size_t)max_batch;
+  // stem input: 4 channels, 3-pixel border, slack on the right/bottom for the kx=7 / ky pad taps
+  e->sHip = height + 6; e->sWip = (width + 8 + 1) & ~1;
+  e->Hs = out_dim(height, 7, 2, 3); e->Ws = out_dim(width, 7, 2, 3);
+  e->stem_in_bytes = B * e->sHip * e->sWip * 4 * e->esz;
+  CREATE_TRY(hipMalloc(&e->stem_in, e->stem_in_bytes));
+  CREATE_TRY(hipMemset(e->stem_in, 0, e->stem_in_bytes));
+  {
+    const int HoWo = e->Hs * e->Ws;
+    e->stem_tiles = (HoWo + 255) / 256;
+    int span = 1;
+    for (int t = 0; t < e->stem_tiles; ++t) {
+      const int m0 = t * 256, me = std::min(m0 + 256, HoWo);
+      span = std::max(span, (me - 1) / e->Ws - m0 / e->Ws + 1);
+    }
+    e->stem_rows = 2 * (span - 1) + 7;
+    e->stem_lds = (size_t)7 * 64 * 64 + (size_t)e->stem_rows * e->sWip * 8;
+    if (dtype != FLOPE_DT_F32 && e->stem_lds > kLdsMax) {
+      int rc = fail(nullptr, FLOPE_EINVAL, "flope_create: crop too wide for the stem kernel's LDS patch"); flope_destroy(e); return rc;
+    }
+  }
+  auto add_buf = [&](int C, int h, int w) {
+    Buf b; b.C = C; b.h = h; b.w = w; b.bytes = B * (h + 2) * (w + 2) * C * e->esz;
+    e->bufs.push_back(b);
+    return (int)e->bufs.size() - 1;
+  };
+  const int b_stem = add_buf(64, e->Hs, e->Ws);
+  const int Hq = out_dim(e->Hs, 3, 2, 1), Wq = out_dim(e->Ws, 3, 2, 1);
+  const int b_pool = add_buf(64, Hq, Wq);
+  e->stage_buf[FLOPE_STAGE_STEM] = b_stem; e->stage_buf[FLOPE_STAGE_POOL] = b_pool;
+  int cur = b_pool, ch = 64, hh = Hq, ww = Wq;
+  const int couts[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 2, 2};
+  for (int li = 0; li < 4; ++li)
+    for (int bi = 0; bi < 2; ++bi) {
+      const int s = bi == 0 ? strides[li] : 1, co = couts[li];
+      const int ho = out_dim(hh, 3, s, 1), wo = out_dim(ww, 3, s, 1);
+      const std::string p = "base.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      const int b_mid = add_buf(co, ho, wo);
+      Conv c1; c1.name = p + ".conv1"; c1.bn = p + ".bn1"; c1.cin = ch; c1.cout = co; c1.k = 3; c1.stride = s;
+      c1.in_buf = cur; c1.out_buf = b_mid; c1.hin = hh; c1.win = ww; c1.hout = ho; c1.wout = wo; c1.relu = 1;
+      e->convs.push_back(c1);
+      int res = cur;
+      if (bi == 0 && (s != 1 || ch != co)) {
+        const int b_ds = add_buf(co, ho, wo);
+        Conv cd; cd.name = p + ".downsample.0"; cd.bn = p + ".downsample.1"; cd.cin = ch; cd.cout = co; cd.k = 1; cd.stride = s;
+        cd.in_buf = cur; cd.out_buf = b_ds; cd.hin = hh; cd.win = ww; cd.hout = ho; cd.wout = wo; cd.relu = 0;
+        e->convs.push_back(cd);
+        res = b_ds;
+      }
+      const int b_out = add_buf(co, ho, wo);
+      Conv c2; c2.name = p + ".conv2"; c2.bn = p + ".bn2"; c2.cin = co; c2.cout = co; c2.k = 3; c2.stride = 1;
+      c2.in_buf = b_mid; c2.out_buf = b_out; c2.res_buf = res; c2.hin = ho; c2.win = wo; c2.hout = ho; c2.wout = wo; c2.relu = 1;
+      e->convs.push_back(c2);
+      e->stage_buf[FLOPE_STAGE_LAYER(li + 1, bi)] = b_out;
+      cur = b_out; ch = co; hh = ho; ww = wo;
+    }
+  e->final_buf = cur;
+  if (hh < 1 || ww < 1) { int rc = fail(nullptr, FLOPE_EINVAL, "flope_create: crop too small"); flope_destroy(e); return rc; }
+  for (Buf& b : e->bufs) {
+    CREATE_TRY(hipMalloc(&b.ptr, b.bytes));
+    CREATE_TRY(hipMemset(b.ptr, 0, b.bytes));          // the zero ring is written exactly once
+  }
+  CREATE_TRY(hipMalloc((void**)&e->feat, B * 512 * sizeof(float)));
+  CREATE_TRY(hipMalloc((void**)&e->hidden, B * (size_t)e->bod * sizeof(float)));
+  CREATE_TRY(hipMalloc((void**)&e->r9_scratch, B * 9 * sizeof(float)));
+  CREATE_TRY(hipDeviceSynchronize());
+#undef CREATE_TRY
+  rebuild_plan(e);
+  *out = e;
+  return FLOPE_OK;
+}
+
+extern "C" int flope_destroy(flope_handle e) {
+  if (!e) return FLOPE_OK;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
+  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); }
+  void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch};
+  for (void* p : singles) if (p) hipFree(p);
+  delete e;
+  return FLOPE_OK;
+}
+
+extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
+  if (!e || !name) return fail(e, FLOPE_EINVAL, "flope_set_option: NULL argument");
+  int prev;
+  if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
+  else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
+  else return fail(e, FLOPE_EINVAL, std::string("flope_set_option: unknown option ") + name);
+  rebuild_plan(e);
+  return prev;
+}
+
+extern "C" int flope_load_weights(flope_handle e, int n, const char* const* names, const float* const* host_ptrs,
+                                  const int* ndims, const int64_t* const* shapes) {
+  if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_load_weights: NULL handle");
+  if (n < 0 || (n > 0 && (!names || !host_ptrs || !ndims || !shapes)))
+    return fail(e, FLOPE_EINVAL, "flope_load_weights: NULL argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  e->weights_loaded = false;
+  Tensors ts;
+  for (int i = 0; i < n; ++i) {
+    if (!names[i] || !host_ptrs[i] || ndims[i] < 0 || ndims[i] > 8 || (ndims[i] > 0 && !shapes[i]))
+      return fail(e, FLOPE_EINVAL, "flope_load_weights: malformed entry " + std::to_string(i));
+    std::vector<int64_t> shp(shapes[i], shapes[i] + ndims[i]);
+    ts.t[names[i]] = std::make_pair(host_ptrs[i], shp);
+  }
+  std::vector<float> wf, bf;
+  int rc;
+  // stem
+  if ((rc = fold(e, ts, "base.conv1", "base.bn1", 64, 3, 7, &wf, &bf)) != 0) return rc;
+  if ((rc = upload(e, bf, (void**)&e->stem_bias)) != 0) return rc;
+  if (e->dtype == FLOPE_DT_F32) { if ((rc = upload(e, naive_layout(wf, 64, 3, 7), (void**)&e->stem_w_naive)) != 0) return rc; }
+  else { if ((rc = upload(e, pack_stem(wf, e->dtype), &e->stem_w)) != 0) return rc; }
+  for (Conv& c : e->convs) {
+    if ((rc = fold(e, ts, c.name, c.bn, c.cout, c.cin, c.k, &wf, &bf)) != 0) return rc;
+    if ((rc = upload(e, bf, (void**)&c.bias)) != 0) return rc;
+    if (e->dtype == FLOPE_DT_F32) { if ((rc = upload(e, naive_layout(wf, c.cout, c.cin, c.k), (void**)&c.w_naive)) != 0) return rc; }
+    else { if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc; }
+  }
+  // head (fp32 as stored)
+  const float* w1 = ts.get(e, "base.fc.0.weight", {e->bod, 512}, &rc); if (!w1) return rc;
+  const float* b1 = ts.get(e, "base.fc.0.bias", {e->bod}, &rc); if (!b1) return rc;
+  const float* w2 = ts.get(e, "fc_rot.weight", {9, e->bod}, &rc); if (!w2) return rc;
+  const float* b2 = ts.get(e, "fc_rot.bias", {9}, &rc); if (!b2) return rc;
+  auto chk = [&](const float* p, size_t cnt, const char* nm) {
+    for (size_t i = 0; i < cnt; ++i) if (!std::isfinite(p[i])) return fail(e, FLOPE_EWEIGHTS, std::string("non-finite value in ") + nm);
+    return 0;
+  };
+  if ((rc = chk(w1, (size_t)e->bod * 512, "base.fc.0.weight")) || (rc = chk(b1, e->bod, "base.fc.0.bias")) ||
+      (rc = chk(w2, (size_t)9 * e->bod, "fc_rot.weight")) || (rc = chk(b2, 9, "fc_rot.bias"))) return rc;
+  if ((rc = upload(e, std::vector<float>(w1, w1 + (size_t)e->bod * 512), (void**)&e->W1)) != 0) return rc;
+  if ((rc = upload(e, std::vector<float>(b1, b1 + e->bod), (void**)&e->b1)) != 0) return rc;
+  if ((rc = upload(e, std::vector<float>(w2, w2 + (size_t)9 * e->bod), (void**)&e->W2)) != 0) return rc;
+  if ((rc = upload(e, std::vector<float>(b2, b2 + 9), (void**)&e->b2)) != 0) return rc;
+  HIP_TRY(e, hipDeviceSynchronize());
+  e->weights_loaded = true;
+  return FLOPE_OK;
+}
+
+// trunk: crop batch -> last BasicBlock output + pooled features
+static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batch, void* stream) {
+  if (!e->weights_loaded) return fail(e, FLOPE_ESTATE, "forward before flope_load_weights");
+  if (!x_dev) return fail(e, FLOPE_EINVAL, "forward: x_dev is NULL");
+  if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "forward: batch must be within 1..max_batch");
+  if (in_format < 0 || in_format > 3) return fail(e, FLOPE_EINVAL, "forward: unknown input format");
+  const int dt = e->dtype;
+  K_TRY(e, "prep_input", flope_prep_input_launch(x_dev, in_format, batch, e->H, e->W, e->stem_in, e->sHip, e->sWip, dt, stream));
+  const Buf& bs = e->bufs[e->stage_buf[FLOPE_STAGE_STEM]];
+  const Buf& bp = e->bufs[e->stage_buf[FLOPE_STAGE_POOL]];
+  if (dt == FLOPE_DT_F32) {
+    NaiveConvP p; memset(&p, 0, sizeof(p));
+    p.in = (const float*)e->stem_in; p.out = (float*)bs.ptr; p.w = e->stem_w_naive; p.bias = e->stem_bias;
+    p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Cin_stored = 4; p.Cin = 3; p.Ho = e->Hs; p.Wo = e->Ws;
+    p.Hop = e->Hs + 2; p.Wop = e->Ws + 2; p.Cout = 64; p.KH = 7; p.KW = 7; p.stride = 2; p.in_off = 0; p.relu = 1;
+    K_TRY(e, "stem (fp32)", flope_naive_conv_launch(&p, stream));
+  } else {
+    StemP p; memset(&p, 0, sizeof(p));
+    p.in = e->stem_in; p.out = bs.ptr; p.w = e->stem_w; p.bias = e->stem_bias;
+    p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Ho = e->Hs; p.Wo = e->Ws;
+    p.tiles_per_image = e->stem_tiles; p.patch_rows_max = e->stem_rows;
+    K_TRY(e, "stem", flope_stem_launch(&p, dt, e->stem_lds, stream));
+  }
+  {
+    PoolP p; p.in = bs.ptr; p.out = bp.ptr; p.B = batch; p.Hip = bs.h + 2; p.Wip = bs.w + 2; p.C = 64; p.Ho = bp.h; p.Wo = bp.w;
+    K_TRY(e, "maxpool", flope_maxpool_launch(&p, dt, stream));
+  }
+  for (const Conv& c : e->convs) {
+    if (dt == FLOPE_DT_F32) {
+      NaiveConvP p; memset(&p, 0, sizeof(p));
+      p.in = (const float*)e->bufs[c.in_buf].ptr; p.out = (float*)e->bufs[c.out_buf].ptr;
+      p.res = c.res_buf >= 0 ? (const float*)e->bufs[c.res_buf].ptr : nullptr;
+      p.w = c.w_naive; p.bias = c.bias;
+      p.B = batch; p.Hip = c.hin + 2; p.Wip = c.win + 2; p.Cin_stored = c.cin; p.Cin = c.cin; p.Ho = c.hout; p.Wo = c.wout;
+      p.Hop = c.hout + 2; p.Wop = c.wout + 2; p.Cout = c.cout; p.KH = c.k; p.KW = c.k; p.stride = c.stride;
+      p.in_off = c.k == 3 ? 0 : 1; p.relu = c.relu;
+      K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
+    } else {
+      ConvP p; conv_params(e, c, batch, &p);
+      K_TRY(e, c.name.c_str(), flope_conv_mfma_launch(&p, dt, c.cfg, c.patch, c.lds, stream));
+    }
+  }
+  const Buf& bl = e->bufs[e->final_buf];
+  K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, e->feat, batch, bl.h, bl.w, 512, dt, stream));
+  K_TRY(e, "fc1", flope_fc1_launch(e->feat, e->W1, e->b1, e->hidden, batch, 512, e->bod, stream));
+  e->last_batch = batch;
+  return FLOPE_OK;
+}
+
+extern "C" int flope_forward(flope_handle e, const void* x_dev, int in_format, int batch, float* r9_dev, float* R_dev,
+                             void* stream) {
+  if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_forward: NULL handle");
+  int rc = run_trunk(e, x_dev, in_format, batch, stream);
+  if (rc) return rc;
+  K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(e->hidden, e->W2, e->b2, r9_dev ? r9_dev : e->r9_scratch, R_dev, batch, e->bod, stream));
+  return FLOPE_OK;
+}
+
+extern "C" int flope_extract_features(flope_handle e, const void* x_dev, int in_format, int batch, float* feat_dev,
+                                      void* stream) {
+  if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_extract_features: NULL handle");
+  if (!feat_dev) return fail(e, FLOPE_EINVAL, "flope_extract_features: feat_dev is NULL");
+  int rc = run_trunk(e, x_dev, in_format, batch, stream);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(feat_dev, e->hidden, (size_t)batch * e->bod * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return FLOPE_OK;
+}
+
+extern "C" int flope_read_stage(flope_handle e, int stage, int batch, float* dst_dev, int64_t* dims_out, void* stream) {
+  if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_read_stage: NULL handle");
+  if (!dst_dev || !dims_out) return fail(e, FLOPE_EINVAL, "flope_read_stage: NULL argument");
+  if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "flope_read_stage: bad batch");
+  if (stage == FLOPE_STAGE_FEAT || stage == FLOPE_STAGE_HIDDEN) {
+    const int nn = stage == FLOPE_STAGE_FEAT ? 512 : e->bod;
+    dims_out[0] = batch; dims_out[1] = nn; dims_out[2] = 1; dims_out[3] = 1;
+    HIP_TRY(e, hipMemcpyAsync(dst_dev, stage == FLOPE_STAGE_FEAT ? e->feat : e->hidden, (size_t)batch * nn * sizeof(float),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FLOPE_OK;
+  }
+  if (stage < 0 || stage > 9) return fail(e, FLOPE_EINVAL, "flope_read_stage: unknown stage");
+  const Buf& b = e->bufs[e->stage_buf[stage]];
+  dims_out[0] = batch; dims_out[1] = b.C; dims_out[2] = b.h; dims_out[3] = b.w;
+  K_TRY(e, "read_stage", flope_read_stage_launch(b.ptr, dst_dev, batch, b.C, b.h, b.w, e->dtype, stream));
+  return FLOPE_OK;
+}
+
+extern "C" double flope_forward_flops(flope_handle e, int batch) {
+  if (!e) return 0.0;
+  double macs = (double)e->Hs * e->Ws * 64 * 147;
+  for (const Conv& c : e->convs) macs += (double)c.hout * c.wout * c.cout * c.cin * c.k * c.k;
+  macs += 512.0 * e->bod + 9.0 * e->bod;
+  return 2.0 * macs * batch;
+}
+
+extern "C" int flope_forward_launches(flope_handle e) { return e ? (int)e->convs.size() + 6 : 0; }
+
+// plan introspection for DESIGN.md / tests: writes one line per conv into buf
+extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
+  if (!e || !buf || buflen < 1) return FLOPE_EINVAL;
+  std::string s;
+  char line[256];
+  snprintf(line, sizeof line, "stem: tiles/img=%d rows=%d lds=%zu\n", e->stem_tiles, e->stem_rows, e->stem_lds);
+  s += line;
+  for (const Conv& c : e->convs) {
+    snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
+             c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.per_image, c.rows_max, c.lds);
+    s += line;
+  }
+  snprintf(buf, buflen, "%s", s.c_str());
+  return FLOPE_OK;
+}

@@ -1,0 +1,107 @@
+// Host-side weight preparation shared by the engine (engine.hip) and the CPU test
+// harness (tests/host_harness): 16-bit conversions (round to nearest even) and the
+// MFMA/LDS-image weight packers.  Plain C++, no HIP.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#define FLOPE_DT_BF16_ 0
+
+namespace flope_host {
+
+// ---- host-side 16-bit conversions (round to nearest even) ---------------------
+inline uint16_t f32_to_bf16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+inline uint16_t f32_to_f16(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x0200u : 0u));
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // overflows to inf after rounding
+  if (x < 0x33000001u) return (uint16_t)sign;                        // rounds to zero
+  int exp = (int)(x >> 23) - 127;
+  uint32_t man = (x & 0x7fffffu) | 0x800000u;
+  int shift;
+  uint32_t hexp;
+  if (exp < -14) { shift = 13 + (-14 - exp); hexp = 0; }            // subnormal half
+  else { shift = 13; hexp = (uint32_t)(exp + 15); }
+  const uint32_t lsb = 1u << shift, half = lsb >> 1;
+  uint32_t q = man >> shift;
+  const uint32_t rem = man & (lsb - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  uint32_t h;
+  if (hexp == 0) h = q;                                              // may carry into exponent 1: fine
+  else h = ((hexp - 1) << 10) + q;                                   // q includes the implicit bit (0x400)
+  return (uint16_t)(sign | h);
+}
+
+inline uint16_t cvt16(float f, int dtype) { return dtype == FLOPE_DT_BF16_ ? f32_to_bf16(f) : f32_to_f16(f); }
+
+
+// ---- weight packing -----------------------------------------------------------
+// Row order inside a 64-channel wave range (NT = 4 channel tiles): LDS row ct*16 + r
+// holds channel (r>>2)*16 + ct*4 + (r&3), so that MFMA D rows 4g..4g+3 of tile ct are
+// channels 16g + 4ct .. +3 and a lane's 16 accumulators are 16 consecutive channels.
+inline int lds_row_to_channel(int rl) {
+  const int range = rl / 64, in = rl % 64, ct = in / 16, r = in % 16;
+  return range * 64 + (r >> 2) * 16 + ct * 4 + (r & 3);
+}
+
+// folded conv weights wf[cout][cin][k][k] -> [ntile][chunk*ntaps + tap][BN rows][64 k] images
+inline std::vector<uint16_t> pack_conv(const std::vector<float>& wf, int cout, int cin, int k, int dtype) {
+  const int BN = cout == 64 ? 64 : 128, ntiles = cout / BN, ntaps = k * k, nchunks = cin / 64;
+  std::vector<uint16_t> out((size_t)cout * cin * ntaps);
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int tap = 0; tap < ntaps; ++tap) {
+        const size_t tile = ((size_t)nt * nchunks * ntaps + (size_t)ch * ntaps + tap) * BN * 64;
+        const int ky = tap / k, kx = tap % k;
+        for (int rl = 0; rl < BN; ++rl) {
+          const int co = nt * BN + lds_row_to_channel(rl);
+          for (int kk = 0; kk < 64; ++kk) {
+            const int ci = ch * 64 + kk;
+            const float v = wf[(((size_t)co * cin + ci) * k + ky) * k + kx];
+            const int slot = (kk >> 3) ^ ((rl >> 1) & 7);
+            out[tile + (size_t)rl * 64 + slot * 8 + (kk & 7)] = cvt16(v, dtype);
+          }
+        }
+      }
+  return out;
+}
+
+// stem weights wf[64][3][7][7] -> [7 ky][64 rows][32 k = kx*4 + c] images (64-byte rows,
+// slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1})
+inline std::vector<uint16_t> pack_stem(const std::vector<float>& wf, int dtype) {
+  static const int h[4] = {0, 2, 3, 1};
+  std::vector<uint16_t> out((size_t)7 * 64 * 32, cvt16(0.f, dtype));
+  for (int ky = 0; ky < 7; ++ky)
+    for (int rl = 0; rl < 64; ++rl) {
+      const int co = lds_row_to_channel(rl);
+      for (int kk = 0; kk < 32; ++kk) {
+        const int kx = kk >> 2, c = kk & 3;
+        const float v = (kx < 7 && c < 3) ? wf[(((size_t)co * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
+        const int slot = (kk >> 3) ^ h[(rl >> 2) & 3];
+        out[((size_t)ky * 64 + rl) * 32 + slot * 8 + (kk & 7)] = cvt16(v, dtype);
+      }
+    }
+  return out;
+}
+
+inline std::vector<float> naive_layout(const std::vector<float>& wf, int cout, int cin, int k) {
+  std::vector<float> out((size_t)cout * cin * k * k);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+          out[(((size_t)ky * k + kx) * cin + ci) * cout + co] = wf[(((size_t)co * cin + ci) * k + ky) * k + kx];
+  return out;
+}
+
+
+}  // namespace flope_host

@@ -1,0 +1,303 @@
+// Max-pool, global average pool and the fp32 regression head + special Procrustes.
+//
+// Reference call sites (all eval-mode semantics):
+//   maxpool      torchvision ResNet._forward_impl (MaxPool2d k3 s2 p1) via posenet.py:25
+//   avgpool      base.avgpool = AdaptiveAvgPool2d(1)                  posenet.py:12
+//   fc.0 + ReLU  base.fc = Sequential(Linear(512,2048), ReLU), F.relu posenet.py:13-16,26
+//   fc_rot       Linear(2048, 9)                                      posenet.py:19,33
+//   Procrustes   roma.special_procrustes(x.reshape(-1,3,3))           utils/conversion.py:54-58
+//   yaw-null     nullify_yaw_batch                                    utils/mvg.py:240-251
+//   Rt compose   Rt[:,:3,:3]=R; Rt[:,:3,3]=xyz                        fast_pose_predictor.py:142-144
+// The whole head is fp32 (fp64 inside the 4x4 eigen-solve): it is 0.06 % of the
+// FLOPs and carries the 1e-3 rotation tolerance.
+#include "common.h"
+#include "pose_math.h"
+
+// ---------------------------------------------------------------------------
+// 3x3 / s2 / p1 max-pool on zero-bordered NHWC.  Inputs are post-ReLU (>= 0), so
+// the zero border is equivalent to the reference's -inf padding.
+template <typename T> struct Vec8;   // 8 consecutive channels
+template <> struct Vec8<bf16_t> { typedef u32x4 type; };
+template <> struct Vec8<f16_t> { typedef u32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ void max8(u32x4& a, const u32x4 b) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float lo = fmaxf(unpack_lo<T>(a[q]), unpack_lo<T>(b[q]));
+    const float hi = fmaxf(unpack_hi<T>(a[q]), unpack_hi<T>(b[q]));
+    a[q] = pack2<T>(lo, hi);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolP p) {
+  const int cg = p.C / 8;                                  // 16-byte channel groups
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * cg;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cg);
+    size_t r = i / cg;
+    const int wo = (int)(r % p.Wo); r /= p.Wo;
+    const int ho = (int)(r % p.Ho);
+    const int b = (int)(r / p.Ho);
+    const char* src = (const char*)p.in + ((((size_t)b * p.Hip + 2 * ho) * p.Wip + 2 * wo) * p.C + c8 * 8) * 2;
+    const size_t rowB = (size_t)p.Wip * p.C * 2, pixB = (size_t)p.C * 2;
+    u32x4 m = *(const u32x4*)src;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        if (dy | dx) max8<T>(m, *(const u32x4*)(src + dy * rowB + dx * pixB));
+    char* dst = (char*)p.out + ((((size_t)b * (p.Ho + 2) + ho + 1) * (p.Wo + 2) + wo + 1) * p.C + c8 * 8) * 2;
+    *(u32x4*)dst = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_f32_kernel(const PoolP p) {
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * p.C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % p.C);
+    size_t r = i / p.C;
+    const int wo = (int)(r % p.Wo); r /= p.Wo;
+    const int ho = (int)(r % p.Ho);
+    const int b = (int)(r / p.Ho);
+    const float* src = (const float*)p.in + (((size_t)b * p.Hip + 2 * ho) * p.Wip + 2 * wo) * p.C + c;
+    float m = 0.f;
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, src[((size_t)dy * p.Wip + dx) * p.C]);
+    ((float*)p.out)[(((size_t)b * (p.Ho + 2) + ho + 1) * (p.Wo + 2) + wo + 1) * p.C + c] = m;
+  }
+}
+
+extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream) {
+  const size_t work = (size_t)p->B * p->Ho * p->Wo * (dtype == 2 ? p->C : p->C / 8);
+  const int grid = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, *p);
+  else if (dtype == 1) hipLaunchKernelGGL(maxpool_kernel<f16_t>, dim3(grid), dim3(256), 0, st, *p);
+  else hipLaunchKernelGGL(maxpool_f32_kernel, dim3(grid), dim3(256), 0, st, *p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Global average pool: padded NHWC [B][h+2][w+2][C] -> float [B][C].
+// One block per image; thread t sums channel pair (2t, 2t+1) when 16-bit.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const void* in, float* out, int h, int w, int C) {
+  const int b = blockIdx.x;
+  const int Wp = w + 2;
+  const float inv = 1.f / (float)(h * w);
+  for (int c2 = threadIdx.x; c2 < C / 2; c2 += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int y = 0; y < h; ++y) {
+      const unsigned* row = (const unsigned*)((const char*)in + ((((size_t)b * (h + 2) + y + 1) * Wp + 1) * C) * 2) + c2;
+      for (int x = 0; x < w; ++x) {
+        const unsigned v = row[(size_t)x * (C / 2)];
+        s0 += unpack_lo<T>(v);
+        s1 += unpack_hi<T>(v);
+      }
+    }
+    out[(size_t)b * C + 2 * c2] = s0 * inv;
+    out[(size_t)b * C + 2 * c2 + 1] = s1 * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool_f32_kernel(const float* in, float* out, int h, int w, int C) {
+  const int b = blockIdx.x;
+  const int Wp = w + 2;
+  const float inv = 1.f / (float)(h * w);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) s += in[(((size_t)b * (h + 2) + y + 1) * Wp + x + 1) * C + c];
+    out[(size_t)b * C + c] = s * inv;
+  }
+}
+
+extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, int w, int C, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(B), dim3(256), 0, st, in, out, h, w, C);
+  else if (dtype == 1) hipLaunchKernelGGL(avgpool_kernel<f16_t>, dim3(B), dim3(256), 0, st, in, out, h, w, C);
+  else hipLaunchKernelGGL(avgpool_f32_kernel, dim3(B), dim3(256), 0, st, (const float*)in, out, h, w, C);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// fc.0 + ReLU: hidden[b][n] = relu(sum_k feat[b][k] * W1[n][k] + b1[n]) on the
+// exact-fp32 MFMA v_mfma_f32_16x16x4_f32 (A = W1 rows, B = images).
+// One wave owns 16 outputs x 64 images.  Each lane loads 16 contiguous bytes of
+// its W1 row / feature row per 16-deep K block and feeds element s to MFMA step s
+// on BOTH operands (lane (r, g) supplies k = k0 + 4g + s), so the K order inside a
+// block is permuted identically for A and B and the sum is unchanged.
+__global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ feat, const float* __restrict__ W1,
+                                                  const float* __restrict__ b1, float* __restrict__ hidden,
+                                                  int B, int K, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int ntile = blockIdx.x * 4 + wave;
+  const int n0 = ntile * 16;
+  const int img0 = blockIdx.y * 64;
+  if (n0 >= N) return;
+  const float* wrow = W1 + (size_t)(n0 + r16) * K + 4 * g;
+  const float* frow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) frow[t] = feat + (size_t)min(img0 + t * 16 + r16, B - 1) * K + 4 * g;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const f32x4 a = *(const f32x4*)(wrow + k0);
+    f32x4 bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[t] = *(const f32x4*)(frow[t] + k0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bv[t][s], acc[t], 0, 0, 0);
+  }
+  // D: col = lane&15 = image, row = 4*(lane>>4)+reg = output n
+  const f32x4 bias = *(const f32x4*)(b1 + n0 + 4 * g);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int img = img0 + t * 16 + r16;
+    if (img < B) {
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = fmaxf(acc[t][q] + bias[q], 0.f);
+      *(f32x4*)(hidden + (size_t)img * N + n0 + 4 * g) = o;
+    }
+  }
+}
+
+// generic fallback when K % 16 != 0 or N % 16 != 0 (non-default backbone_out_dim)
+__global__ __launch_bounds__(256) void fc1_simple_kernel(const float* feat, const float* W1, const float* b1,
+                                                         float* hidden, int B, int K, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * N) return;
+  const int n = (int)(i % N), b = (int)(i / N);
+  float s = b1[n];
+  for (int k = 0; k < K; ++k) s = fmaf(feat[(size_t)b * K + k], W1[(size_t)n * K + k], s);
+  hidden[i] = fmaxf(s, 0.f);
+}
+
+extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* b1, float* hidden, int B, int K,
+                                int N, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (K % 16 == 0 && N % 16 == 0) {
+    const dim3 grid((N / 16 + 3) / 4, (B + 63) / 64);
+    hipLaunchKernelGGL(fc1_kernel, grid, dim3(256), 0, st, feat, W1, b1, hidden, B, K, N);
+  } else {
+    const size_t total = (size_t)B * N;
+    hipLaunchKernelGGL(fc1_simple_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feat, W1, b1,
+                       hidden, B, K, N);
+  }
+  return (int)hipGetLastError();
+}
+
+// fc_rot + Procrustes: one wave per image.
+__global__ __launch_bounds__(256) void fc2_procrustes_kernel(const float* __restrict__ hidden,
+                                                             const float* __restrict__ W2,
+                                                             const float* __restrict__ b2, float* r9_out,
+                                                             float* R_out, int B, int K) {
+  const int lane = threadIdx.x & 63;
+  const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (img >= B) return;
+  float acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+  const float* h = hidden + (size_t)img * K;
+  if ((K & 3) == 0) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 hv = *(const f32x4*)(h + k);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const f32x4 wv = *(const f32x4*)(W2 + (size_t)j * K + k);
+        acc[j] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+      }
+    }
+  } else {
+    for (int k = lane; k < K; k += 64)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[j] = fmaf(h[k], W2[(size_t)j * K + k], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+  }
+  if (lane == 0) {
+    float M[9], R[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) M[j] = acc[j] + b2[j];
+    if (r9_out)
+      for (int j = 0; j < 9; ++j) r9_out[(size_t)img * 9 + j] = M[j];
+    if (R_out) {
+      procrustes3x3(M, R);
+      for (int j = 0; j < 9; ++j) R_out[(size_t)img * 9 + j] = R[j];
+    }
+  }
+}
+
+extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9,
+                                           float* R, int B, int K, void* stream) {
+  hipLaunchKernelGGL(fc2_procrustes_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden, W2, b2, r9,
+                     R, B, K);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void procrustes_kernel(const float* M, float* R, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float m[9], r[9];
+  for (int j = 0; j < 9; ++j) m[j] = M[(size_t)i * 9 + j];
+  procrustes3x3(m, r);
+  for (int j = 0; j < 9; ++j) R[(size_t)i * 9 + j] = r[j];
+}
+
+__global__ __launch_bounds__(64) void nullify_yaw_kernel(const float* R, float* O, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float r[9], o[9];
+  for (int j = 0; j < 9; ++j) r[j] = R[(size_t)i * 9 + j];
+  nullify_yaw3x3(r, o);
+  for (int j = 0; j < 9; ++j) O[(size_t)i * 9 + j] = o[j];
+}
+
+__global__ __launch_bounds__(64) void compose_pose_kernel(const float* R, const float* xyz, int n, int nullify,
+                                                          float* Rt) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float r[9], o[9];
+  for (int j = 0; j < 9; ++j) r[j] = R[(size_t)i * 9 + j];
+  if (nullify) nullify_yaw3x3(r, o);
+  else for (int j = 0; j < 9; ++j) o[j] = r[j];
+  float* t = Rt + (size_t)i * 16;
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) t[a * 4 + b] = o[a * 3 + b];
+    t[a * 4 + 3] = xyz ? xyz[(size_t)i * 3 + a] : 0.f;
+  }
+  t[12] = 0.f; t[13] = 0.f; t[14] = 0.f; t[15] = 1.f;
+}
+
+extern "C" int flope_procrustes(const float* M_dev, float* R_dev, int n, void* stream) {
+  if (n < 0 || (n > 0 && (!M_dev || !R_dev))) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(procrustes_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, M_dev, R_dev, n);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int flope_nullify_yaw(const float* R_dev, float* out_dev, int n, void* stream) {
+  if (n < 0 || (n > 0 && (!R_dev || !out_dev))) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(nullify_yaw_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, R_dev, out_dev, n);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int flope_compose_pose(const float* R_dev, const float* xyz_dev, int n, int nullify_yaw, float* Rt_dev,
+                                  void* stream) {
+  if (n < 0 || (n > 0 && (!R_dev || !Rt_dev))) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(compose_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, R_dev, xyz_dev, n,
+                     nullify_yaw, Rt_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,298 @@
+// Data-format kernels either side of the trunk (all HBM-bandwidth work):
+//   * crop batch -> stem input (4-channel, 3-pixel-bordered NHWC in the trunk dtype)
+//   * internal activation -> float32 NCHW (parity tests, flope_read_stage)
+//   * crop + Lanczos-4 resize + mask multiply (reference fast_pose_predictor.py:108-123,
+//     pose_predictor.py:138-153, scripts/test_posenet.py:124-140,
+//     scripts/generate_metrics_utils.py:17-35)
+//   * depth statistics + back-projection (image_manipulation.py:21-96, mvg.py:387-408)
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void store4(void* dst, float a, float b, float c);
+template <> __device__ __forceinline__ void store4<bf16_t>(void* dst, float a, float b, float c) {
+  *(u32x2*)dst = u32x2{pack2<bf16_t>(a, b), pack2<bf16_t>(c, 0.f)};
+}
+template <> __device__ __forceinline__ void store4<f16_t>(void* dst, float a, float b, float c) {
+  *(u32x2*)dst = u32x2{pack2<f16_t>(a, b), pack2<f16_t>(c, 0.f)};
+}
+template <> __device__ __forceinline__ void store4<float>(void* dst, float a, float b, float c) {
+  *(f32x4*)dst = f32x4{a, b, c, 0.f};
+}
+
+// in_format: 0 f32 NCHW, 1 bf16 NHWC, 2 f16 NHWC, 3 u8 NHWC (include/flope_amd.h)
+template <typename T>
+__global__ __launch_bounds__(256) void prep_input_kernel(const void* x, int in_format, int B, int H, int W,
+                                                         void* out, int Hip, int Wip) {
+  const size_t total = (size_t)B * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int xx = (int)(i % W);
+    const size_t r = i / W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    float c0, c1, c2;
+    if (in_format == 0) {
+      const float* p = (const float*)x + ((size_t)b * 3 * H + yy) * W + xx;
+      c0 = p[0]; c1 = p[(size_t)H * W]; c2 = p[(size_t)2 * H * W];
+    } else if (in_format == 1) {
+      const unsigned short* p = (const unsigned short*)x + i * 3;
+      c0 = to_f32(__builtin_bit_cast(bf16_t, p[0])); c1 = to_f32(__builtin_bit_cast(bf16_t, p[1]));
+      c2 = to_f32(__builtin_bit_cast(bf16_t, p[2]));
+    } else if (in_format == 2) {
+      const unsigned short* p = (const unsigned short*)x + i * 3;
+      c0 = to_f32(__builtin_bit_cast(f16_t, p[0])); c1 = to_f32(__builtin_bit_cast(f16_t, p[1]));
+      c2 = to_f32(__builtin_bit_cast(f16_t, p[2]));
+    } else {
+      const unsigned char* p = (const unsigned char*)x + i * 3;
+      c0 = (float)p[0] / 255.0f; c1 = (float)p[1] / 255.0f; c2 = (float)p[2] / 255.0f;
+    }
+    char* dst = (char*)out + (((size_t)b * Hip + yy + 3) * Wip + xx + 3) * (4 * sizeof(T));
+    store4<T>(dst, c0, c1, c2);
+  }
+}
+
+extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip,
+                                       int Wip, int dtype, void* stream) {
+  const size_t total = (size_t)B * H * W;
+  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(prep_input_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, in_format, B, H, W, out, Hip, Wip);
+  else if (dtype == 1) hipLaunchKernelGGL(prep_input_kernel<f16_t>, dim3(grid), dim3(256), 0, st, x, in_format, B, H, W, out, Hip, Wip);
+  else hipLaunchKernelGGL(prep_input_kernel<float>, dim3(grid), dim3(256), 0, st, x, in_format, B, H, W, out, Hip, Wip);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// padded NHWC (border 1) -> float32 NCHW
+template <typename T>
+__global__ __launch_bounds__(256) void read_stage_kernel(const void* in, float* out, int B, int C, int h, int w) {
+  const size_t total = (size_t)B * C * h * w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % w);
+    size_t r = i / w;
+    const int y = (int)(r % h); r /= h;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    const size_t src = (((size_t)b * (h + 2) + y + 1) * (w + 2) + x + 1) * C + c;
+    out[i] = to_f32(((const T*)in)[src]);
+  }
+}
+
+extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype,
+                                       void* stream) {
+  const size_t total = (size_t)B * C * h * w;
+  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(read_stage_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, in, out, B, C, h, w);
+  else if (dtype == 1) hipLaunchKernelGGL(read_stage_kernel<f16_t>, dim3(grid), dim3(256), 0, st, in, out, B, C, h, w);
+  else hipLaunchKernelGGL(read_stage_kernel<float>, dim3(grid), dim3(256), 0, st, in, out, B, C, h, w);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Crop + Lanczos-4 resize + mask multiply.
+//
+// cv2.resize(src, (S,S), interpolation=INTER_LANCZOS4) on uint8 (OpenCV 4.10, not
+// vendored by the reference; restated from the published algorithm): for output index
+// d the source coordinate is f = (d + 0.5) * (n_src / S) - 0.5, s = floor(f), t = f - s;
+// the eight taps s-3 .. s+4 (clamped to the crop: edge replication) get weights
+// w_i = sinc-Lanczos(a=4) evaluated through the 45-degree rotation recurrence, normalised
+// to sum 1 in float, then quantised to int16 fixed point (x 2048, round-half-even,
+// saturated).  Horizontal then vertical passes accumulate in int32 without intermediate
+// rounding; the result is (acc + 2^21) >> 22 saturated to uint8.  Because no rounding
+// happens between the passes the 8x8 direct sum below is bit-identical to the two-pass
+// form.  Then (fast_pose_predictor.py:118,121): out = img * (mask / 255.0) / 255.0.
+__device__ __forceinline__ void lanczos4_coeffs(float x, short* c16) {
+  const double s45 = 0.70710678118654752440084436210485;
+  const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  const double PI = 3.1415926535897932384626433832795;
+  float coeffs[8];
+  float sum = 0.f;
+  const double y0 = -(x + 3) * PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+  for (int i = 0; i < 8; ++i) {
+    const float y0_ = (x + 3 - i);
+    if (fabsf(y0_) >= 1e-6f) {
+      const double y = -y0_ * PI * 0.25;
+      coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    } else {
+      coeffs[i] = 1e30f;
+    }
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; ++i) {
+    const float v = coeffs[i] * sum * 2048.f;
+    int q = (int)rintf(v);                       // cvRound: round half to even
+    q = q > 32767 ? 32767 : (q < -32768 ? -32768 : q);
+    c16[i] = (short)q;
+  }
+}
+
+// one thread = one output pixel (3 channels + mask)
+__global__ __launch_bounds__(256) void crop_resize_mask_kernel(const unsigned char* __restrict__ frame,
+                                                               const unsigned char* __restrict__ mask, int FH, int FW,
+                                                               const int* __restrict__ boxes, int n, int S,
+                                                               int out_format, void* out) {
+  const size_t total = (size_t)n * S * S;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int dx = (int)(i % S);
+    const size_t r = i / S;
+    const int dy = (int)(r % S);
+    const int b = (int)(r / S);
+    const int xmin = boxes[b * 4], ymin = boxes[b * 4 + 1], xmax = boxes[b * 4 + 2], ymax = boxes[b * 4 + 3];
+    const int cw = xmax - xmin, ch = ymax - ymin;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (cw > 0 && ch > 0) {
+      // cv::resize computes scale in double, the coordinate in float
+      const double scx = (double)cw / S, scy = (double)ch / S;
+      float fx = (float)((dx + 0.5) * scx - 0.5);
+      float fy = (float)((dy + 0.5) * scy - 0.5);
+      const int sx = (int)floorf(fx), sy = (int)floorf(fy);
+      fx -= sx; fy -= sy;
+      short ax[8], ay[8];
+      lanczos4_coeffs(fx, ax);
+      lanczos4_coeffs(fy, ay);
+      int a0 = 0, a1 = 0, a2 = 0, am = 0;
+      for (int ky = 0; ky < 8; ++ky) {
+        int yy = sy - 3 + ky;
+        yy = yy < 0 ? 0 : (yy >= ch ? ch - 1 : yy);
+        const unsigned char* frow = frame + ((size_t)(ymin + yy) * FW + xmin) * 3;
+        const unsigned char* mrow = mask + (size_t)(ymin + yy) * FW + xmin;
+        int h0 = 0, h1 = 0, h2 = 0, hm = 0;
+        for (int kx = 0; kx < 8; ++kx) {
+          int xx = sx - 3 + kx;
+          xx = xx < 0 ? 0 : (xx >= cw ? cw - 1 : xx);
+          const int w = ax[kx];
+          h0 += frow[xx * 3] * w; h1 += frow[xx * 3 + 1] * w; h2 += frow[xx * 3 + 2] * w;
+          hm += mrow[xx] * w;
+        }
+        const int wv = ay[ky];
+        a0 += h0 * wv; a1 += h1 * wv; a2 += h2 * wv; am += hm * wv;
+      }
+      auto fin = [](int v) { v = (v + (1 << 21)) >> 22; return v < 0 ? 0 : (v > 255 ? 255 : v); };
+      const float mk = (float)fin(am) / 255.0f;
+      o0 = (float)fin(a0) * mk / 255.0f;
+      o1 = (float)fin(a1) * mk / 255.0f;
+      o2 = (float)fin(a2) * mk / 255.0f;
+    }
+    if (out_format == 0) {
+      float* o = (float*)out + ((size_t)b * 3 * S + dy) * S + dx;
+      o[0] = o0; o[(size_t)S * S] = o1; o[(size_t)2 * S * S] = o2;
+    } else if (out_format == 1) {
+      bf16_t* o = (bf16_t*)out + i * 3;
+      o[0] = from_f32<bf16_t>(o0); o[1] = from_f32<bf16_t>(o1); o[2] = from_f32<bf16_t>(o2);
+    } else {
+      f16_t* o = (f16_t*)out + i * 3;
+      o[0] = from_f32<f16_t>(o0); o[1] = from_f32<f16_t>(o1); o[2] = from_f32<f16_t>(o2);
+    }
+  }
+}
+
+extern "C" int flope_crop_resize_mask(const uint8_t* frame_dev, const uint8_t* mask_dev, int frame_h, int frame_w,
+                                      const int32_t* boxes_dev, int n, int size, int out_format, void* out_dev,
+                                      void* stream) {
+  if (n < 0 || size <= 0 || frame_h <= 0 || frame_w <= 0 || out_format < 0 || out_format > 2) return -1;
+  if (n == 0) return 0;
+  if (!frame_dev || !mask_dev || !boxes_dev || !out_dev) return -1;
+  const size_t total = (size_t)n * size * size;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(crop_resize_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, frame_dev, mask_dev,
+                     frame_h, frame_w, boxes_dev, n, size, out_format, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------
+// Depth: valid = (near < d < far) & (mask > 128); eroded by cv2's 10x10 MORPH_ELLIPSE
+// (anchor (5,5), out-of-frame taps ignored = erode's default +inf constant border).
+// Element rows (OpenCV getStructuringElement: dx = round(c * sqrt(1 - dy^2/r^2)), r=c=5):
+//   i: 0 -> col 5 | 1,9 -> 2..8 | 2,8 -> 1..9 | 3..7 -> 0..9
+__constant__ signed char kEllipseLo[10] = {5, 2, 1, 0, 0, 0, 0, 0, 1, 2};
+__constant__ signed char kEllipseHi[10] = {5, 8, 9, 9, 9, 9, 9, 9, 9, 8};
+
+template <typename DT>
+__global__ __launch_bounds__(256) void depth_valid_kernel(const DT* depth, const unsigned char* mask,
+                                                          size_t npix, float div, float nearp, float farp,
+                                                          unsigned char* valid) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+    const float d = (float)depth[i] / div;
+    valid[i] = (d > nearp && d < farp && mask[i] > 128) ? 1 : 0;
+  }
+}
+
+// one block per box: masked mean of depth over eroded-valid pixels
+template <typename DT>
+__global__ __launch_bounds__(256) void depth_box_kernel(const DT* depth, const unsigned char* valid,
+                                                        int FH, int FW, float div, const int* boxes, float fx, float fy,
+                                                        float cx, float cy, float* depth_val, int* reliable,
+                                                        float* xyz) {
+  const int b = blockIdx.x;
+  const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
+  // numpy slicing semantics of depth[hmin:hmax, wmin:wmax] for in-frame, non-negative boxes
+  const int xs = max(x0, 0), ys = max(y0, 0), xe = min(x1, FW), ye = min(y1, FH);
+  const int bw = max(xe - xs, 0), bh = max(ye - ys, 0);
+  double sum = 0.0;
+  int cnt = 0;
+  for (int i = threadIdx.x; i < bw * bh; i += 256) {
+    const int x = xs + i % bw, y = ys + i / bw;
+    bool ok = true;
+    for (int ey = 0; ey < 10 && ok; ++ey) {
+      const int yy = y + ey - 5;
+      if (yy < 0 || yy >= FH) continue;
+      for (int ex = kEllipseLo[ey]; ex <= kEllipseHi[ey]; ++ex) {
+        const int xx = x + ex - 5;
+        if (xx < 0 || xx >= FW) continue;
+        if (!valid[(size_t)yy * FW + xx]) { ok = false; break; }
+      }
+    }
+    if (ok) {
+      const float dm = (float)depth[(size_t)y * FW + x] / div;   // metres, float32 like the reference
+      sum += (double)(dm * 1000.0f);                              // reference averages millimetres
+      ++cnt;
+    }
+  }
+  __shared__ double ssum[256];
+  __shared__ int scnt[256];
+  ssum[threadIdx.x] = sum; scnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int c = scnt[0];
+    const double dv = c > 0 ? (ssum[0] / c) / 1000.0 : 0.0;
+    depth_val[b] = (float)dv;
+    reliable[b] = c >= 50 ? 1 : 0;
+    // uv = centre of the (un-squared) box; depth is the ray length (mvg.py:387-408)
+    const double u = (x0 + x1) * 0.5, v = (y0 + y1) * 0.5;
+    const double xn = (u - cx) / fx, yn = (v - cy) / fy;
+    const double z = dv / sqrt(xn * xn + yn * yn + 1.0);
+    xyz[b * 3] = (float)(xn * z); xyz[b * 3 + 1] = (float)(yn * z); xyz[b * 3 + 2] = (float)z;
+  }
+}
+
+extern "C" int flope_depth_lift(const void* depth_dev, int depth_format, const uint8_t* mask_dev, int frame_h,
+                                int frame_w, float depth_div, float near_plane, float far_plane, const int32_t* boxes_dev, int n,
+                                const float* K4_host, uint8_t* scratch_dev, float* depth_val_dev,
+                                int32_t* reliable_dev, float* xyz_dev, void* stream) {
+  if (n < 0 || frame_h <= 0 || frame_w <= 0 || !(depth_div > 0.f) || !K4_host || depth_format < 0 || depth_format > 1) return -1;
+  if (n == 0) return 0;
+  if (!depth_dev || !mask_dev || !boxes_dev || !scratch_dev || !depth_val_dev || !reliable_dev || !xyz_dev) return -1;
+  const size_t npix = (size_t)frame_h * frame_w;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+  if (depth_format == 0) {
+    const unsigned short* d = (const unsigned short*)depth_dev;
+    hipLaunchKernelGGL(depth_valid_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, d, mask_dev, npix, depth_div,
+                       near_plane, far_plane, scratch_dev);
+    hipLaunchKernelGGL(depth_box_kernel<unsigned short>, dim3(n), dim3(256), 0, st, d, scratch_dev, frame_h, frame_w,
+                       depth_div, boxes_dev, K4_host[0], K4_host[1], K4_host[2], K4_host[3], depth_val_dev,
+                       reliable_dev, xyz_dev);
+  } else {
+    const float* d = (const float*)depth_dev;
+    hipLaunchKernelGGL(depth_valid_kernel<float>, dim3(grid), dim3(256), 0, st, d, mask_dev, npix, depth_div,
+                       near_plane, far_plane, scratch_dev);
+    hipLaunchKernelGGL(depth_box_kernel<float>, dim3(n), dim3(256), 0, st, d, scratch_dev, frame_h, frame_w, depth_div,
+                       boxes_dev, K4_host[0], K4_host[1], K4_host[2], K4_host[3], depth_val_dev, reliable_dev, xyz_dev);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

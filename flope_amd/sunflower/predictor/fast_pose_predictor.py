@@ -1,0 +1,109 @@
+"""Drop-in for the reference's ``sunflower/predictor/fast_pose_predictor.py``
+(``FastPosePredictor``, :19-156): detect -> squarify -> depth -> crop batch -> PoseResNet
+-> Procrustes -> yaw-null -> Rt.  Everything after the detector runs on the GPU in one
+stream with a single device->host copy of the final ``[N,4,4]`` poses.
+
+Detector: the reference constructs ``ultralytics.YOLO(yolo_path)`` (:36).  ultralytics and
+its weights are third-party and absent here, so ``yolo_path`` may also be a callable
+``image -> (bbox int16 [N,4], mask uint8 [H,W])`` (the contract of ``get_bbox_mask``);
+a path string is handed to ultralytics if that package is importable.
+"""
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from flope_amd import _lib
+from flope_amd import engine as _engine
+from sunflower.models.posenet import PoseResNet
+from sunflower.utils.io import read_intrinsics_yaml_to_K_h_w
+from sunflower.utils.mvg import bb_in_frame, squarify_bb
+
+
+def select_boxes(boxes, frame_shape):
+    """fast_pose_predictor.py:65-83: keep boxes whose squarified version lies inside the frame.
+    -> (uv [n,2] float64 box centres, sq_bb [n,4] int, good_bb [n,4] int16)"""
+    uv, sq, good = [], [], []
+    for bb in boxes:
+        xmin, ymin, xmax, ymax = (int(v) for v in bb)
+        s = squarify_bb(bb)
+        if not bb_in_frame(s, frame_shape):
+            continue
+        uv.append([(xmax + xmin) / 2, (ymax + ymin) / 2])
+        sq.append(s)
+        good.append([xmin, ymin, xmax, ymax])
+    return (np.array(uv, dtype=np.float64).reshape(-1, 2), np.array(sq, dtype=np.int64).reshape(-1, 4),
+            np.array(good).astype(np.int16).reshape(-1, 4))
+
+
+def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_size=512, near=0.1, far=2.5,
+                          device=None):
+    """Shared tail of both predictors (fast_pose_predictor.py:65-156, pose_predictor.py:90-186)."""
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise RuntimeError("flope_amd predictors run on HIP devices only")
+    uv, sq_bb, good_bb = select_boxes(boxes, rgb.shape)
+    if good_bb.shape[0] == 0:
+        return None
+    frame_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
+    mask_d = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(dev)
+    depth_np = np.ascontiguousarray(depth)
+    if depth_np.dtype == np.uint16:
+        depth_d = torch.from_numpy(depth_np.view(np.int16)).to(dev)        # bits travel unchanged
+    else:
+        depth_d = torch.from_numpy(depth_np.astype(np.float32)).to(dev)
+    K4 = (K[0][0], K[1][1], K[0][2], K[1][2])
+    _, reliable, xyz = _engine.depth_lift(depth_d, mask_d, torch.from_numpy(good_bb.astype(np.int32)), K4,
+                                          depth_div, near, far)
+    keep = reliable.cpu().numpy()
+    if not keep.any():
+        return None
+    sq_keep = torch.from_numpy(sq_bb[keep].astype(np.int32)).to(dev)
+    xyz = xyz[torch.from_numpy(keep).to(dev)]
+    crops = _engine.crop_resize_mask(frame_d, mask_d, sq_keep, crop_size, _lib.IN_F32_NCHW)
+    _, R = posenet.predict_rotations(crops)
+    Rt = _engine.compose_pose(R, xyz, nullify=True)
+    return Rt.double().cpu().numpy()
+
+
+class FastPosePredictor:
+    def __init__(self, device: str, yolo_path, posenet_path: str, intrin_path: str, debug: bool = False):
+        self.device = device
+        self.debug = debug
+        self.posenet = PoseResNet().to(device)
+        self.posenet.load_state_dict(torch.load(posenet_path, weights_only=True))
+        print(f"Model loaded: {Path(posenet_path).name}")
+        if callable(yolo_path):
+            self.yolo = None
+            self._detector = yolo_path
+        else:
+            try:
+                from ultralytics import YOLO
+            except ImportError as exc:
+                raise ImportError("FastPosePredictor: ultralytics is not installed; pass a callable "
+                                  "image -> (bbox, mask) as yolo_path instead") from exc
+            self.yolo = YOLO(yolo_path).to(device)
+            self._detector = self._yolo_bbox_mask
+            print(f"YOLO loaded: {Path(yolo_path).name}")
+        self.K, self.height, self.width = read_intrinsics_yaml_to_K_h_w(intrin_path)
+        print("FastPosePredictor initialized!")
+
+    def _yolo_bbox_mask(self, image):
+        """fast_pose_predictor.py:44-57 on top of ultralytics (third-party, parity unpinned)."""
+        H, W, _ = image.shape
+        res = self.yolo(image)[0]
+        m = (torch.clip(res.masks.data.sum(dim=0), 0, 1) * 255).to(torch.uint8)
+        # cv2.resize default (bilinear, half-pixel centres) to the frame size
+        m = torch.nn.functional.interpolate(m[None, None].float(), size=(H, W), mode="bilinear",
+                                            align_corners=False)[0, 0]
+        return res.boxes.xyxy.cpu().numpy().astype(np.int16), m.round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+
+    def get_bbox_mask(self, image):
+        """-> (bbox int16 [N,4] xyxy, mask uint8 [H,W])"""
+        return self._detector(image)
+
+    def get_flower_poses(self, rgb, depth):
+        """rgb uint8 [H,W,3], depth uint16 [H,W] (millimetres) -> float64 [N,4,4] | None"""
+        bb, mask = self.get_bbox_mask(rgb)
+        return poses_from_detections(self.posenet, rgb, depth, bb, mask, self.K, depth_div=1000.0,
+                                     device=self.device)

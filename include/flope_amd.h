@@ -1,0 +1,149 @@
+/*
+ * flope_amd.h -- C-ABI of the MI355X-native flower-pose hot path.
+ *
+ * The reference (wvu-irl/flope) has no FFI of its own: its seam is Python
+ * duck-typing on an nn.Module and two predictor classes.  This
+ * header is therefore the build-defined boundary the Python facade
+ * (flope_amd/sunflower/...) binds with ctypes; every entry point names the
+ * reference call it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, a negative FLOPE_E* code otherwise;
+ *     flope_last_error() returns the message of the last failure on the handle
+ *     (or of the last handle-less failure when h == NULL).
+ *   - "dev" pointers are device (HBM) addresses owned by the caller
+ *     (tensor.data_ptr()); "host" pointers are ordinary host memory.
+ *   - kernels are enqueued on the hipStream_t passed as `void* stream`
+ *     (0 = the null stream); nothing synchronises internally and nothing is
+ *     allocated inside flope_forward / flope_procrustes / flope_crop_* /
+ *     flope_depth_* (workspace is allocated by flope_create).
+ *   - a handle is bound to one device and is not thread-safe.
+ */
+#ifndef FLOPE_AMD_H
+#define FLOPE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flope_engine* flope_handle;
+
+/* error codes */
+#define FLOPE_OK            0
+#define FLOPE_EINVAL       -1   /* bad argument / shape */
+#define FLOPE_EHIP         -2   /* a HIP runtime call failed */
+#define FLOPE_ESTATE       -3   /* call order (e.g. forward before load_weights) */
+#define FLOPE_EWEIGHTS     -4   /* state_dict entry missing / wrong shape / not finite */
+
+/* arithmetic type of the trunk (activations + conv weights as stored in HBM;
+ * accumulation, bias, residual add and the whole head are always fp32) */
+#define FLOPE_DT_BF16       0   /* MFMA v_mfma_f32_16x16x32_bf16 */
+#define FLOPE_DT_F16        1   /* MFMA v_mfma_f32_16x16x32_f16  */
+#define FLOPE_DT_F32        2   /* strict mode: plain fp32 direct convolution (no MFMA) */
+
+/* layout / dtype of the crop batch handed to flope_forward */
+#define FLOPE_IN_F32_NCHW   0   /* reference API: float32 [B,3,H,W] in [0,1] (posenet.py:31) */
+#define FLOPE_IN_BF16_NHWC  1   /* bfloat16 [B,H,W,3] in [0,1]  (BASELINE cfg2) */
+#define FLOPE_IN_F16_NHWC   2   /* float16  [B,H,W,3] in [0,1] */
+#define FLOPE_IN_U8_NHWC    3   /* uint8    [B,H,W,3] 0..255, scaled by 1/255 on load */
+
+/* activation taps for flope_read_stage (parity tests) */
+#define FLOPE_STAGE_STEM    0   /* conv1+bn1+relu          [B,64,H/2,W/2] */
+#define FLOPE_STAGE_POOL    1   /* maxpool                 [B,64,H/4,W/4] */
+#define FLOPE_STAGE_LAYER(li, bi)  (2 + ((li) - 1) * 2 + (bi))   /* li 1..4, bi 0..1 */
+#define FLOPE_STAGE_FEAT    10  /* global average pool     [B,512]  */
+#define FLOPE_STAGE_HIDDEN  11  /* fc.0 + ReLU             [B,2048] */
+
+/* ---- life cycle ----------------------------------------------------------
+ * Replaces PoseResNet().to(device)   (sunflower/models/posenet.py:6-22,
+ * fast_pose_predictor.py:31): builds the fixed launch plan and allocates every
+ * activation buffer for crops of height x width up to max_batch.  Never fetches
+ * ImageNet weights (the reference does, posenet.py:10). */
+int flope_create(int device_id, int height, int width, int max_batch, int dtype,
+                 int backbone_out_dim, flope_handle* out);
+int flope_destroy(flope_handle h);
+const char* flope_last_error(flope_handle h);
+
+/* Replaces model.load_state_dict(torch.load(path, weights_only=True))
+ * (scripts/test_posenet.py:51, fast_pose_predictor.py:32).  Entries are host
+ * fp32, contiguous, named exactly as in the reference's 124-entry state_dict
+ * (num_batches_tracked entries may be omitted).  The library folds eval-mode
+ * BatchNorm into each conv, converts to the trunk dtype, repacks into the
+ * MFMA tile order and uploads. */
+int flope_load_weights(flope_handle h, int n, const char* const* names,
+                       const float* const* host_ptrs, const int* ndims,
+                       const int64_t* const* shapes);
+
+/* ---- the hot path ----------------------------------------------------------
+ * Replaces  r9 = model(image_batch); R = procrustes_to_rotmat(r9)
+ * (fast_pose_predictor.py:126-127, scripts/test_posenet.py:142-144).
+ * x_dev: crop batch in `in_format`; r9_dev: float32 [B,9] (may be NULL);
+ * R_dev: float32 [B,9] row-major 3x3 rotations (may be NULL).  batch <= max_batch. */
+int flope_forward(flope_handle h, const void* x_dev, int in_format, int batch,
+                  float* r9_dev, float* R_dev, void* stream);
+
+/* PoseResNet.extract_features (posenet.py:24-29): float32 [B,backbone_out_dim]. */
+int flope_extract_features(flope_handle h, const void* x_dev, int in_format, int batch,
+                           float* feat_dev, void* stream);
+
+/* Stand-alone  roma.special_procrustes(M.reshape(-1,3,3))
+ * (sunflower/utils/conversion.py:54-58): float32 [n,9] -> float32 [n,9]. */
+int flope_procrustes(const float* M_dev, float* R_dev, int n, void* stream);
+
+/* nullify_yaw_batch (sunflower/utils/mvg.py:240-251): R' = R * Rz(atan2(-R01,R00))^T,
+ * float32 [n,9] -> float32 [n,9] (in place allowed). */
+int flope_nullify_yaw(const float* R_dev, float* out_dev, int n, void* stream);
+
+/* Pose assembly (fast_pose_predictor.py:131-144): optional yaw-nullification of R,
+ * then Rt = [[R, xyz],[0,0,0,1]] as float32 [n,16]; xyz_dev float32 [n,3] (NULL -> 0). */
+int flope_compose_pose(const float* R_dev, const float* xyz_dev, int n, int nullify_yaw,
+                       float* Rt_dev, void* stream);
+
+/* Crop-batch assembly (4 copies in the reference: fast_pose_predictor.py:108-123,
+ * pose_predictor.py:138-153, scripts/test_posenet.py:124-140,
+ * scripts/generate_metrics_utils.py:17-35): for each square box
+ * [xmin,ymin,xmax,ymax] crop frame and mask, Lanczos-4 resize both to size x size,
+ * out = img * (mask/255) / 255.  frame_dev uint8 [H,W,3], mask_dev uint8 [H,W],
+ * boxes_dev int32 [n,4]; out_dev float32 [n,3,size,size] (FLOPE_IN_F32_NCHW) or
+ * 16-bit [n,size,size,3] (FLOPE_IN_BF16_NHWC / FLOPE_IN_F16_NHWC). */
+int flope_crop_resize_mask(const uint8_t* frame_dev, const uint8_t* mask_dev,
+                           int frame_h, int frame_w, const int32_t* boxes_dev, int n,
+                           int size, int out_format, void* out_dev, void* stream);
+
+/* Depth statistics + back-projection (image_manipulation.py:39-96, mvg.py:387-408):
+ * valid = (near < d < far) & (mask > 128), eroded by the 10x10 ellipse; per box the
+ * mean of valid depths, count >= 50 => reliable; xyz = K^-1 [u,v,1]^T * d/|K^-1[u,v,1]|.
+ * depth_dev: depth_format 0 = uint16 [H,W] raw units, 1 = float32 [H,W]; metres = value /
+ * depth_div (1000 at fast_pose_predictor.py:90, 10000 at pose_predictor.py:118, 1 for the
+ * float-metres argument of get_depth_value itself), boxes int32 [n,4]
+ * (un-squared boxes), K = {fx,fy,cx,cy}.  Outputs: depth_val float32 [n] (metres),
+ * reliable int32 [n], xyz float32 [n,3].  scratch_dev: >= H*W bytes. */
+int flope_depth_lift(const void* depth_dev, int depth_format, const uint8_t* mask_dev,
+                     int frame_h, int frame_w, float depth_div, float near_plane, float far_plane,
+                     const int32_t* boxes_dev, int n, const float* K4_host,
+                     uint8_t* scratch_dev, float* depth_val_dev, int32_t* reliable_dev,
+                     float* xyz_dev, void* stream);
+
+/* ---- introspection (parity tests / DESIGN.md numbers) ----------------------- */
+/* Copy one internal activation of the LAST forward to float32: conv stages as
+ * NCHW [B,C,h,w]; FEAT / HIDDEN as [B,n].  dims_out[4] receives the shape. */
+int flope_read_stage(flope_handle h, int stage, int batch, float* dst_dev,
+                     int64_t* dims_out, void* stream);
+/* runtime knobs (A/B variants inside one build); returns previous value or <0 */
+int flope_set_option(flope_handle h, const char* name, int value);
+/* algorithmic FLOPs of one forward for `batch` crops (2*MAC, convs + 2 FCs) */
+double flope_forward_flops(flope_handle h, int batch);
+/* number of kernel launches flope_forward enqueues */
+int flope_forward_launches(flope_handle h);
+/* human-readable launch plan (one line per conv: tile config, patch/gather, LDS bytes) */
+int flope_describe_plan(flope_handle h, char* buf, int buflen);
+/* library / build identification */
+const char* flope_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOPE_AMD_H */

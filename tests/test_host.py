@@ -1,0 +1,203 @@
+"""CPU: host logic of the product (no GPU compute): C-ABI exports, pose math shared with
+the head kernels, 16-bit conversions, MFMA weight packers, checkpoint inventory and the
+pure-python parts of the ``sunflower`` mirror."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_ref as P
+from oracle import posenet_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32p = C.POINTER(C.c_float)
+
+
+def _f(a):
+    return a.ctypes.data_as(f32p)
+
+
+# ---- the C-ABI library ---------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    from flope_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "flope_amd.h")).read()
+    declared = set(re.findall(r"\b(flope_[a-z0-9_]+)\s*\(", header))
+    declared.discard("flope_engine")
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.flope_version()
+
+
+def test_create_fails_loudly_without_gpu():
+    from flope_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.flope_create(0, 224, 224, 4, 1, 2048, C.byref(h))
+    assert rc != 0 and not h.value
+    assert "no HIP device" in _lib.last_error(None)
+    from flope_amd.engine import PoseEngine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PoseEngine(224, 224, 4)
+
+
+def test_bad_arguments_are_rejected():
+    from flope_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.flope_create(0, 8, 8, 4, 1, 2048, C.byref(h)) == -1
+    assert lib.flope_create(0, 224, 224, 0, 1, 2048, C.byref(h)) == -1
+    assert lib.flope_create(0, 224, 224, 4, 7, 2048, C.byref(h)) == -1
+    assert lib.flope_procrustes(None, None, 3, None) == -1
+    assert lib.flope_procrustes(None, None, 0, None) == 0
+    assert lib.flope_forward(None, None, 0, 1, None, None, None) == -1
+
+
+# ---- pose math compiled from the same header the kernels use ------------------------------------
+def test_horn_procrustes_matches_svd_oracle(harness):
+    g = torch.Generator().manual_seed(0)
+    M = torch.randn(512, 3, 3, generator=g)
+    M[:64] = torch.from_numpy(np.linalg.qr(np.random.default_rng(1).normal(size=(64, 3, 3)))[0]).float() * 0.7
+    Mn = np.ascontiguousarray(M.numpy().reshape(-1, 9))
+    out = np.empty_like(Mn)
+    harness.hh_procrustes(_f(Mn), _f(out), Mn.shape[0])
+    ref = O.special_procrustes(M.double()).numpy().reshape(-1, 9)
+    sv = O.singular_values(M).numpy()
+    well = (sv[:, 1] + sv[:, 2]) > 0.05           # away from the gauge-degenerate set
+    assert well.sum() > 400
+    np.testing.assert_allclose(out[well], ref[well], atol=2e-5)
+    R = out.reshape(-1, 3, 3).astype(np.float64)
+    np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-5)
+
+
+def test_nullify_yaw_matches_scipy_oracle(harness):
+    from scipy.spatial.transform import Rotation
+    R = Rotation.random(256, random_state=4).as_matrix().astype(np.float32).reshape(-1, 9)
+    R = np.ascontiguousarray(R)
+    out = np.empty_like(R)
+    harness.hh_nullify_yaw(_f(R), _f(out), R.shape[0])
+    ref = P.nullify_yaw_batch(R.reshape(-1, 3, 3).astype(np.float64)).reshape(-1, 9)
+    np.testing.assert_allclose(out, ref, atol=2e-6)
+
+
+def test_sunflower_mvg_mirror_matches_oracle():
+    from sunflower.utils import mvg
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = rng.integers(0, 300, 2); b = a + rng.integers(1, 200, 2)
+        bb = [int(a[0]), int(a[1]), int(b[0]), int(b[1])]
+        assert mvg.squarify_bb(bb) == P.squarify_bb(bb)
+        s = mvg.squarify_bb(bb)
+        assert mvg.bb_in_frame(s, (400, 450, 3)) == P.bb_in_frame(s, (400, 450, 3))
+    bbs = rng.integers(0, 50, (20, 2)); bbs = np.c_[bbs, bbs + rng.integers(1, 100, (20, 2))]
+    assert mvg.filter_very_large_bb(bbs).tolist() == P.filter_very_large_bb(bbs).tolist()
+    K = np.array([[910.0, 0, 640.5], [0, 905.0, 360.2], [0, 0, 1]])
+    uv = rng.uniform(0, 1000, (16, 2)); d = rng.uniform(0.2, 2, 16)
+    np.testing.assert_allclose(mvg.get_points3d(uv, d, K), P.get_points3d(uv, d, K), atol=1e-12)
+    from scipy.spatial.transform import Rotation
+    R = Rotation.random(32, random_state=9).as_matrix()
+    np.testing.assert_allclose(mvg.nullify_yaw_batch(R), P.nullify_yaw_batch(R), atol=1e-12)
+    cam = np.eye(4); cam[:3, :3] = R[0]; cam[:3, 3] = [1, 2, 3]
+    obj = np.tile(np.eye(4), (3, 1, 1)); obj[:, :3, :3] = R[1:4]
+    np.testing.assert_allclose(mvg.pose_cam_to_world(obj, cam), cam @ obj, atol=1e-15)
+
+
+def test_sunflower_loss_mirror_matches_reference_fixture(ref_fixtures):
+    from sunflower.utils.loss import diff_quats
+    dot, ang = diff_quats(torch.from_numpy(ref_fixtures["dq_q1"]), torch.from_numpy(ref_fixtures["dq_q2"]))
+    np.testing.assert_allclose(dot.numpy(), ref_fixtures["dq_dot"], atol=1e-12)
+    np.testing.assert_allclose(ang.numpy(), ref_fixtures["dq_angle"], atol=1e-6)
+
+
+# ---- 16-bit conversions / packers --------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tdt", [(0, torch.bfloat16), (1, torch.float16)])
+def test_cvt16_bit_exact_vs_torch(harness, dtype, tdt):
+    g = torch.Generator().manual_seed(5)
+    vals = torch.cat([torch.randn(20000, generator=g) * s for s in (1e-8, 1e-5, 1e-3, 1.0, 300.0, 7e4)])
+    edge = torch.tensor([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e38, -1e38, 5.96e-8, 2.98e-8, 2.99e-8, 6.1e-5,
+                         float("inf"), -float("inf"), 1.0 + 2 ** -11, 1.0 + 2 ** -8, 1.0 + 3 * 2 ** -9])
+    v = np.ascontiguousarray(torch.cat([vals, edge]).numpy())
+    out = np.empty(v.shape[0], np.uint16)
+    harness.hh_cvt16(_f(v), out.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_long(v.shape[0]), dtype)
+    ref = torch.from_numpy(v).to(tdt).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(out, ref)
+
+
+def test_lds_row_permutation_is_a_bijection_with_consecutive_lane_channels(harness):
+    rows = [harness.hh_lds_row_to_channel(r) for r in range(128)]
+    assert sorted(rows) == list(range(128))
+    # lane group g of a wave owns MFMA rows 4g..4g+3 of each of the 4 channel tiles: channels 16g..16g+15
+    for rng_ in range(2):
+        for g in range(4):
+            ch = [rows[rng_ * 64 + ct * 16 + 4 * g + q] for ct in range(4) for q in range(4)]
+            assert ch == list(range(rng_ * 64 + 16 * g, rng_ * 64 + 16 * g + 16))
+
+
+@pytest.mark.parametrize("cout,cin,k", [(64, 64, 3), (128, 64, 1), (256, 128, 3)])
+def test_pack_conv_is_a_permutation_of_the_weights(harness, cout, cin, k):
+    n = cout * cin * k * k
+    w = (np.arange(n, dtype=np.float32) % 2039) + 1.0          # exactly representable in f16
+    w = w.reshape(cout, cin, k, k)
+    out = np.empty(n, np.uint16)
+    harness.hh_pack_conv(_f(np.ascontiguousarray(w)), cout, cin, k, 1, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    vals = torch.from_numpy(out.view(np.int16)).view(torch.float16).float().numpy()
+    assert np.array_equal(np.sort(vals), np.sort(w.reshape(-1)))
+    # spot check the documented image order: tile (ntile 0, chunk 0, tap 0), LDS row 0 = channel 0
+    BN = 64 if cout == 64 else 128
+    row0 = vals[:64]
+    logical = np.concatenate([row0[((j ^ 0) * 8):((j ^ 0) * 8 + 8)] for j in range(8)])
+    np.testing.assert_array_equal(logical, w[0, :64, 0, 0])
+    # row 2 (swizzle (2>>1)&7 = 1): channel 2, slots XOR 1
+    r = vals[2 * 64:3 * 64]
+    logical = np.concatenate([r[((j ^ 1) * 8):((j ^ 1) * 8 + 8)] for j in range(8)])
+    np.testing.assert_array_equal(logical, w[harness.hh_lds_row_to_channel(2), :64, 0, 0])
+    assert BN in (64, 128)
+
+
+def test_pack_stem_layout(harness):
+    w = np.random.default_rng(0).integers(-64, 64, (64, 3, 7, 7)).astype(np.float32)
+    out = np.empty(7 * 64 * 32, np.uint16)
+    harness.hh_pack_stem(_f(np.ascontiguousarray(w)), 1, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    vals = torch.from_numpy(out.view(np.int16)).view(torch.float16).float().numpy().reshape(7, 64, 32)
+    h = [0, 2, 3, 1]
+    for ky in (0, 3, 6):
+        for rl in (0, 5, 17, 63):
+            co = harness.hh_lds_row_to_channel(rl)
+            row = vals[ky, rl]
+            logical = np.concatenate([row[((s ^ h[(rl >> 2) & 3]) * 8):((s ^ h[(rl >> 2) & 3]) * 8 + 8)] for s in range(4)])
+            expect = np.zeros(32, np.float32)
+            for kx in range(7):
+                for c in range(3):
+                    expect[kx * 4 + c] = w[co, c, ky, kx]
+            np.testing.assert_array_equal(logical, expect)
+
+
+# ---- checkpoint inventory -------------------------------------------------------------------------
+def test_state_dict_inventory(state_dict):
+    from flope_amd.weights import expected_keys, validate_state_dict
+    keys = expected_keys()
+    assert len(keys) == 124 and set(keys) == set(state_dict)
+    assert sum(int(np.prod(s)) for k, s in keys.items() if "running" not in k and "num_batches" not in k) == 12245577
+    validate_state_dict(state_dict)
+    bad = dict(state_dict); bad.pop("fc_rot.bias")
+    with pytest.raises(RuntimeError, match="missing keys"):
+        validate_state_dict(bad)
+    bad = dict(state_dict); bad["fc_rot.bias"] = torch.zeros(8)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        validate_state_dict(bad)
+
+
+def test_facade_module_has_the_reference_key_set(state_dict):
+    from sunflower.models.posenet import PoseResNet
+    m = PoseResNet()
+    assert set(m.state_dict()) == set(state_dict)
+    m.load_state_dict(state_dict)
+    assert sum(p.numel() for p in m.parameters()) == 12245577
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        m(torch.rand(1, 3, 64, 64))

@@ -1,0 +1,135 @@
+"""CPU: the oracle against the golden vectors, hand-derived known answers and the
+fixtures produced by the reference's own importable files."""
+import numpy as np
+import torch
+
+from oracle import pipeline_ref as P
+from oracle import posenet_ref as O
+
+
+# ---- pinned by reference-run fixtures ---------------------------------------------------
+def test_diff_quats_matches_reference_fixture(ref_fixtures):
+    q1, q2 = torch.from_numpy(ref_fixtures["dq_q1"]), torch.from_numpy(ref_fixtures["dq_q2"])
+    dot, ang = O.diff_quats(q1, q2)
+    np.testing.assert_allclose(dot.numpy(), ref_fixtures["dq_dot"], atol=1e-12)
+    np.testing.assert_allclose(ang.numpy(), ref_fixtures["dq_angle"], atol=1e-6)   # acos near |dot| = 1
+    assert np.all(np.abs(ref_fixtures["dq_angle"][:8]) < 1e-4)       # q vs q and q vs -q: same rotation
+
+
+# ---- hand-derived known answers ------------------------------
+def test_squarify_kats():
+    assert P.squarify_bb([10, 20, 50, 40]) == [10, 10, 50, 50]
+    assert P.squarify_bb([0, 0, 10, 5]) == [0, -3, 10, 7]             # odd diff: min gets (d+1)/2
+    assert P.squarify_bb([0, 0, 5, 10]) == [-3, 0, 7, 10]
+    assert P.squarify_bb([3, 4, 9, 10]) == [3, 4, 9, 10]
+
+
+def test_bb_in_frame_kats():
+    shape = (100, 200, 3)
+    assert P.bb_in_frame([0, 0, 200, 100], shape)                     # xmax == w, ymax == h accepted
+    assert not P.bb_in_frame([0, 0, 201, 100], shape)
+    assert not P.bb_in_frame([-1, 0, 10, 10], shape)
+    assert not P.bb_in_frame([0, 0, 10, 101], shape)
+
+
+def test_filter_very_large_bb_kat():
+    bb = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [0, 0, 12, 10], [0, 0, 100, 100]])
+    out = P.filter_very_large_bb(bb)                                  # median area 110 -> drop > 550
+    assert out.tolist() == bb[:3].tolist()
+
+
+def test_get_points3d_kats():
+    K = np.array([[1000.0, 0, 960], [0, 1000.0, 540], [0, 0, 1]])
+    xyz = P.get_points3d(np.array([[960.0, 540.0], [1960.0, 540.0]]), np.array([0.5, 0.5 * np.sqrt(2)]), K)
+    np.testing.assert_allclose(xyz, [[0, 0, 0.5], [0.5, 0, 0.5]], atol=1e-12)   # depth is ray length
+
+
+def test_ellipse_kernel_shape():
+    k = P.ellipse_kernel(10)
+    assert [int(r.sum()) for r in k] == [1, 7, 9, 10, 10, 10, 10, 10, 9, 7]
+    assert k[0, 5] == 1 and k[1, 2] == 1 and k[1, 1] == 0
+
+
+def test_lanczos_identity_and_constant():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    assert np.array_equal(P.resize_lanczos4_u8(img, 32), img)
+    flat = np.full((17, 23), 200, np.uint8)
+    assert np.all(P.resize_lanczos4_u8(flat, 64) == 200)              # weights sum to 2048 exactly? -> constant preserved
+    up = P.resize_lanczos4_u8(img, 64)
+    assert up.shape == (64, 64, 3) and up.dtype == np.uint8
+
+
+# ---- Procrustes ---------------------------------------------------------------------------
+def _rand_rot(n, seed):
+    from scipy.spatial.transform import Rotation
+    return torch.from_numpy(Rotation.random(n, random_state=seed).as_matrix())
+
+
+def test_procrustes_kats():
+    R = _rand_rot(32, 1)
+    np.testing.assert_allclose(O.special_procrustes(R).numpy(), R.numpy(), atol=1e-12)        # M = R
+    np.testing.assert_allclose(O.special_procrustes(3.7 * R).numpy(), R.numpy(), atol=1e-12)  # M = sR
+    refl = R.clone(); refl[:, :, 2] *= -1                                                     # det = -1 input
+    out = O.special_procrustes(refl)
+    np.testing.assert_allclose(torch.det(out).numpy(), 1.0, atol=1e-12)
+    np.testing.assert_allclose((out @ out.transpose(1, 2)).numpy(), np.tile(np.eye(3), (32, 1, 1)), atol=1e-12)
+
+
+def test_procrustes_is_the_frobenius_minimiser():
+    g = torch.Generator().manual_seed(3)
+    M = torch.randn(16, 3, 3, generator=g, dtype=torch.float64)
+    R = O.special_procrustes(M)
+    base = ((R - M) ** 2).sum(dim=(1, 2))
+    for s in range(5):
+        Q = _rand_rot(16, 100 + s)
+        assert torch.all(((Q - M) ** 2).sum(dim=(1, 2)) >= base - 1e-12)
+
+
+def test_nullify_yaw_closed_form_matches_scipy():
+    R = _rand_rot(64, 5).numpy()
+    ref = P.nullify_yaw_batch(R)
+    a = np.arctan2(-R[:, 0, 1], R[:, 0, 0])
+    Rz = np.zeros_like(R); Rz[:, 0, 0] = np.cos(a); Rz[:, 0, 1] = -np.sin(a); Rz[:, 1, 0] = np.sin(a); Rz[:, 1, 1] = np.cos(a); Rz[:, 2, 2] = 1
+    np.testing.assert_allclose(R @ Rz.transpose(0, 2, 1), ref, atol=1e-12)
+    np.testing.assert_allclose(ref[:, 0, 1], 0, atol=1e-12)
+    np.testing.assert_allclose(ref[:, :, 2], R[:, :, 2], atol=1e-12)   # flower axis preserved
+
+
+# ---- network vs committed goldens (BASELINE cfg1) ---------------------------------------------
+def test_cfg1_forward_matches_goldens(state_dict, golden_cfg1):
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    x = torch.rand(16, 3, 224, 224)
+    assert abs(x.double().sum().item() - golden_cfg1["x_checksum"][0]) < 1e-6
+    st = O.forward_stages(state_dict, x)
+    np.testing.assert_allclose(st["r9"].numpy(), golden_cfg1["r9"], atol=1e-5)
+    R = O.procrustes_to_rotmat(st["r9"]).numpy()
+    np.testing.assert_allclose(R, golden_cfg1["R"], atol=1e-5)
+    rows = P.detection_rows(np.tile(np.array([[0, 0, 224, 224]]), (16, 1)), R)
+    assert rows.shape == (16, 15)
+    np.testing.assert_allclose(rows, golden_cfg1["rows"], atol=1e-5)
+    np.testing.assert_allclose(rows[:, 4:6], 112.0)
+    for k in ("stem", "pool", "layer1.1", "layer4.1"):
+        np.testing.assert_allclose(st[k][:2, ::7, ::5, ::5].numpy(), golden_cfg1["stage_" + k], atol=2e-4, rtol=1e-4)
+
+
+def test_emulated_16bit_paths_stay_close(state_dict):
+    torch.manual_seed(1)
+    x = torch.rand(2, 3, 96, 96)
+    ref = O.forward_stages(state_dict, x)["r9"]
+    f16 = O.forward_stages_emulated(state_dict, x, torch.float16)["r9"]
+    b16 = O.forward_stages_emulated(state_dict, x, torch.bfloat16)["r9"]
+    assert (f16 - ref).abs().max() < 2e-3
+    assert (b16 - ref).abs().max() < 2e-2
+    assert (f16 - ref).abs().max() < (b16 - ref).abs().max()
+
+
+def test_fold_bn_equals_bn(state_dict):
+    torch.manual_seed(2)
+    x = torch.rand(1, 64, 12, 12)
+    sd = state_dict
+    w, b = O.fold_bn(sd["base.layer1.0.conv1.weight"], sd, "base.layer1.0.bn1")
+    y1 = torch.nn.functional.conv2d(x, w, b, padding=1)
+    y2 = O._bn(torch.nn.functional.conv2d(x, sd["base.layer1.0.conv1.weight"], None, padding=1), sd, "base.layer1.0.bn1")
+    np.testing.assert_allclose(y1.numpy(), y2.numpy(), atol=2e-5)
