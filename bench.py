@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: poses/sec of the flower-pose hot path on N MI355X (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f16|bf16] [--crop 224] [--batch 256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch: 256 synthetic 224x224x3 crops, 16-bit
+NHWC, already resident in HBM -> PoseResNet trunk (MFMA convs) -> fp32 head -> special
+Procrustes -> yaw-null + 4x4 pose assembly (BASELINE configs[1]).  Ranks own independent
+batches (weak scaling, no collective on the data path); the finished [K*256,16] pose records
+are all-gathered ONCE over RCCL inside the timed region (BASELINE configs[3]).  Rank 0 prints
+one JSON line.
+
+The timed loop is un-instrumented.  The `roofline` object comes from a second pass of the same
+steps in the engine's profile mode (HIP events around every launch on the launch stream); the
+`cpu_baseline` object is the CPU oracle (torch fp32, eval mode) timed on the host cores on a
+bounded sample -- a reported baseline, never part of the product path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(crop: int, budget_s: float = 15.0):
+    """Oracle forward + Procrustes on the host cores, B = 16."""
+    from flope_amd.weights import synthetic_state_dict
+    from oracle import posenet_ref as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = synthetic_state_dict(0)
+    torch.manual_seed(0)
+    x = torch.rand(16, 3, crop, crop)
+    with torch.no_grad():
+        for _ in range(2):
+            O.procrustes_to_rotmat(O.forward(sd, x))
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 40):
+            t0 = time.perf_counter()
+            O.procrustes_to_rotmat(O.forward(sd, x))
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(16 / med, 2), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} x (16 crops {crop}x{crop} fp32, torch CPU eval-mode oracle + SVD Procrustes), median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default=os.environ.get("FLOPE_DTYPE", "f16"), choices=["f16", "bf16"])
+    ap.add_argument("--crop", type=int, default=224)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16/f16 measurement")
+    args = ap.parse_args()
+
+    from flope_amd import distributed as D
+    from flope_amd import engine as E
+    from flope_amd.weights import synthetic_state_dict
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no HIP device visible (the product path has no CPU fallback)")
+    rank, world, local = D.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, S, K, W = args.batch, args.crop, args.steps, args.warmup
+    sd = synthetic_state_dict(0)
+
+    def build(dtype):
+        eng = E.PoseEngine(S, S, B, dtype, device=dev)
+        eng.load_state_dict(sd)
+        tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+        g = torch.Generator().manual_seed(1234 + rank)          # per-rank synthetic crops
+        x = torch.rand(B, S, S, 3, generator=g).to(tdt).to(dev)
+        return eng, x, (2 if dtype == "f16" else 1)
+
+    def run_steps(eng, x, fmt, n, poses, R, xyz):
+        lib, stream = eng.lib, torch.cuda.current_stream(dev).cuda_stream
+        for i in range(n):
+            eng.forward_into(x, fmt, None, R)
+            # yaw-null + [R|t] assembly straight into this step's slice of the pose buffer
+            rc = lib.flope_compose_pose(R.data_ptr(), xyz.data_ptr(), B, 1, poses[i % poses.shape[0]].data_ptr(), stream)
+            if rc:
+                raise RuntimeError("compose_pose failed")
+
+    def measure(dtype):
+        eng, x, fmt = build(dtype)
+        R = torch.empty(B, 9, device=dev)
+        xyz = torch.zeros(B, 3, device=dev)                      # translation comes from depth (cfg3); zeros here
+        poses = torch.empty(max(K, 1), B, 16, device=dev)
+        run_steps(eng, x, fmt, W, poses, R, xyz)
+        D.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run_steps(eng, x, fmt, K, poses, R, xyz)
+        allp = D.gather_poses(poses.view(K * B, 16))
+        D.barrier(); torch.cuda.synchronize(dev)
+        dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+        assert allp.shape == (world * K * B, 16)
+        return eng, x, fmt, dt, R, xyz, poses
+
+    eng, x, fmt, dt, R, xyz, poses = measure(args.dtype)
+    value = world * K * B / dt
+
+    out = {
+        "metric": "poses_per_sec", "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"PoseResNet (ResNet-18 trunk + fp32 head) forward + special Procrustes + pose assembly, "
+                               f"batch {B} x {S}x{S}x3 16-bit NHWC crops resident in HBM per GPU (BASELINE configs[1]); "
+                               f"one RCCL all-gather of the poses per run when N>1 (configs[3])",
+                   "batch_per_gpu": B, "global_batch": B * world, "crop": S, "parallelism": f"dp{world}",
+                   "weights": "synthetic_state_dict(seed 0), eval-mode BN folded",
+                   "gflop_per_pose": round(eng.flops(1) / 1e9, 4)},
+    }
+
+    if rank == 0:
+        # ---- roofline: per-launch HIP-event times of the same steps (profile mode) ------------------
+        eng.set_option("profile", 1)
+        info = eng.launch_info(B)
+        acc = [0.0] * len(info)
+        nprof = max(4, min(K, 16))
+        run_steps(eng, x, fmt, 2, poses, R, xyz)
+        for _ in range(nprof):
+            run_steps(eng, x, fmt, 1, poses, R, xyz)
+            for i, ms in enumerate(eng.profile_read()):
+                acc[i] += ms
+        eng.set_option("profile", 0)
+        per_kernel = {}
+        for (layer, kern, fl), ms in zip(info, acc):
+            k = per_kernel.setdefault(kern, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            k["ms"] += ms / nprof; k["flops"] += fl; k["launches"] += 1
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+        d = per_kernel[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": dom, "launches_per_step": d["launches"],
+                           "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                           "gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2),
+                           "step_frac_of_peak": round(value / world * eng.flops(1) / 1e12 / PEAK_TFLOPS, 4)}
+        out["kernels_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
+        # ---- parity of this very configuration against the oracle on a sample ---------------------
+        from oracle import posenet_ref as O
+        xs = x[:8].float().permute(0, 3, 1, 2).cpu()
+        Rref = O.procrustes_to_rotmat(O.forward(sd, xs))
+        eng.forward_into(x, fmt, None, R)
+        torch.cuda.synchronize(dev)
+        out["rot_err_vs_oracle"] = {"max_abs_R": float((R[:8].view(8, 3, 3).cpu() - Rref).abs().max()),
+                                    "max_angle_deg": float(O.geodesic_deg(R[:8].view(8, 3, 3).cpu(), Rref).max()),
+                                    "sample": "8 crops of the bench batch vs fp32 CPU oracle"}
+    eng.close()
+
+    if not args.no_alt and world == 1:
+        alt = "bf16" if args.dtype == "f16" else "f16"
+        eng2, _, _, dt2, _, _, _ = measure(alt)
+        out["alt_dtype"] = {"dtype": alt, "value": round(K * B / dt2, 1), "ms_per_step": round(dt2 / K * 1e3, 4)}
+        eng2.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(S)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

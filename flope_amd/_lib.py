@@ -35,6 +35,8 @@ SIGNATURES = {
     "flope_set_option": (_I, [_P, C.c_char_p, _I]),
     "flope_forward_flops": (_D, [_P, _I]),
     "flope_forward_launches": (_I, [_P]),
+    "flope_profile_read": (_I, [_P, C.POINTER(_F), _I]),
+    "flope_launch_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_D)]),
     "flope_describe_plan": (_I, [_P, C.c_char_p, _I]),
     "flope_version": (C.c_char_p, []),
 }

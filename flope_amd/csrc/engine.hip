@@ -74,7 +74,9 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0;
+  std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
+  int ev_n = 0;
   int last_batch = 0;
   std::string err;
 };
@@ -99,6 +101,12 @@ int fail(flope_engine* e, int code, const std::string& msg) {
     int _s = (call);                                                                       \
     if (_s != 0)                                                                           \
       return fail(e, FLOPE_EHIP, std::string(what) + ": " + hipGetErrorString((hipError_t)_s)); \
+  } while (0)
+
+#define MARK(e, stream)                                                                    \
+  do {                                                                                     \
+    if ((e)->opt_profile && (e)->ev_n < (int)(e)->ev.size())                               \
+      HIP_TRY(e, hipEventRecord((e)->ev[(e)->ev_n++], (hipStream_t)(stream)));             \
   } while (0)
 
 int out_dim(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
@@ -341,6 +349,8 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
   CREATE_TRY(hipMalloc((void**)&e->feat, B * 512 * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->hidden, B * (size_t)e->bod * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->r9_scratch, B * 9 * sizeof(float)));
+  e->ev.resize(e->convs.size() + 8);
+  for (hipEvent_t& ev : e->ev) CREATE_TRY(hipEventCreate(&ev));
   CREATE_TRY(hipDeviceSynchronize());
 #undef CREATE_TRY
   rebuild_plan(e);
@@ -356,6 +366,7 @@ extern "C" int flope_destroy(flope_handle e) {
   for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); }
   void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch};
   for (void* p : singles) if (p) hipFree(p);
+  for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   delete e;
   return FLOPE_OK;
 }
@@ -365,6 +376,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   int prev;
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
+  else if (!strcmp(name, "profile")) { prev = e->opt_profile; e->opt_profile = value != 0; e->ev_n = 0; return prev; }
   else return fail(e, FLOPE_EINVAL, std::string("flope_set_option: unknown option ") + name);
   rebuild_plan(e);
   return prev;
@@ -424,6 +436,8 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "forward: batch must be within 1..max_batch");
   if (in_format < 0 || in_format > 3) return fail(e, FLOPE_EINVAL, "forward: unknown input format");
   const int dt = e->dtype;
+  e->ev_n = 0;
+  MARK(e, stream);
   K_TRY(e, "prep_input", flope_prep_input_launch(x_dev, in_format, batch, e->H, e->W, e->stem_in, e->sHip, e->sWip, dt, stream));
   const Buf& bs = e->bufs[e->stage_buf[FLOPE_STAGE_STEM]];
   const Buf& bp = e->bufs[e->stage_buf[FLOPE_STAGE_POOL]];
@@ -432,16 +446,19 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
     p.in = (const float*)e->stem_in; p.out = (float*)bs.ptr; p.w = e->stem_w_naive; p.bias = e->stem_bias;
     p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Cin_stored = 4; p.Cin = 3; p.Ho = e->Hs; p.Wo = e->Ws;
     p.Hop = e->Hs + 2; p.Wop = e->Ws + 2; p.Cout = 64; p.KH = 7; p.KW = 7; p.stride = 2; p.in_off = 0; p.relu = 1;
+    MARK(e, stream);
     K_TRY(e, "stem (fp32)", flope_naive_conv_launch(&p, stream));
   } else {
     StemP p; memset(&p, 0, sizeof(p));
     p.in = e->stem_in; p.out = bs.ptr; p.w = e->stem_w; p.bias = e->stem_bias;
     p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Ho = e->Hs; p.Wo = e->Ws;
     p.tiles_per_image = e->stem_tiles; p.patch_rows_max = e->stem_rows;
+    MARK(e, stream);
     K_TRY(e, "stem", flope_stem_launch(&p, dt, e->stem_lds, stream));
   }
   {
     PoolP p; p.in = bs.ptr; p.out = bp.ptr; p.B = batch; p.Hip = bs.h + 2; p.Wip = bs.w + 2; p.C = 64; p.Ho = bp.h; p.Wo = bp.w;
+    MARK(e, stream);
     K_TRY(e, "maxpool", flope_maxpool_launch(&p, dt, stream));
   }
   for (const Conv& c : e->convs) {
@@ -453,14 +470,18 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
       p.B = batch; p.Hip = c.hin + 2; p.Wip = c.win + 2; p.Cin_stored = c.cin; p.Cin = c.cin; p.Ho = c.hout; p.Wo = c.wout;
       p.Hop = c.hout + 2; p.Wop = c.wout + 2; p.Cout = c.cout; p.KH = c.k; p.KW = c.k; p.stride = c.stride;
       p.in_off = c.k == 3 ? 0 : 1; p.relu = c.relu;
+      MARK(e, stream);
       K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
     } else {
       ConvP p; conv_params(e, c, batch, &p);
+      MARK(e, stream);
       K_TRY(e, c.name.c_str(), flope_conv_mfma_launch(&p, dt, c.cfg, c.patch, c.lds, stream));
     }
   }
   const Buf& bl = e->bufs[e->final_buf];
+  MARK(e, stream);
   K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, e->feat, batch, bl.h, bl.w, 512, dt, stream));
+  MARK(e, stream);
   K_TRY(e, "fc1", flope_fc1_launch(e->feat, e->W1, e->b1, e->hidden, batch, 512, e->bod, stream));
   e->last_batch = batch;
   return FLOPE_OK;
@@ -471,7 +492,9 @@ extern "C" int flope_forward(flope_handle e, const void* x_dev, int in_format, i
   if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_forward: NULL handle");
   int rc = run_trunk(e, x_dev, in_format, batch, stream);
   if (rc) return rc;
+  MARK(e, stream);
   K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(e->hidden, e->W2, e->b2, r9_dev ? r9_dev : e->r9_scratch, R_dev, batch, e->bod, stream));
+  MARK(e, stream);
   return FLOPE_OK;
 }
 
@@ -512,6 +535,43 @@ extern "C" double flope_forward_flops(flope_handle e, int batch) {
 }
 
 extern "C" int flope_forward_launches(flope_handle e) { return e ? (int)e->convs.size() + 6 : 0; }
+
+// profile mode ("profile" option): per-launch GPU time of the LAST flope_forward, from HIP
+// events recorded on the caller's stream around every launch.  Synchronises on the last event.
+extern "C" int flope_profile_read(flope_handle e, float* ms_out, int cap) {
+  if (!e || !ms_out) return fail(e, FLOPE_EINVAL, "flope_profile_read: NULL argument");
+  if (!e->opt_profile || e->ev_n < 2) return fail(e, FLOPE_ESTATE, "flope_profile_read: no profiled forward (set option \"profile\" first)");
+  HIP_TRY(e, hipEventSynchronize(e->ev[e->ev_n - 1]));
+  const int n = std::min(cap, e->ev_n - 1);
+  for (int i = 0; i < n; ++i) HIP_TRY(e, hipEventElapsedTime(&ms_out[i], e->ev[i], e->ev[i + 1]));
+  return n;
+}
+
+// launch idx of flope_forward: "layer|kernel" label and its algorithmic FLOPs for `batch` crops
+extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name, int name_cap, double* flops) {
+  if (!e || !name || name_cap < 1 || !flops) return fail(e, FLOPE_EINVAL, "flope_launch_info: NULL argument");
+  const int nc = (int)e->convs.size();
+  if (idx < 0 || idx >= nc + 6) return fail(e, FLOPE_EINVAL, "flope_launch_info: bad index");
+  const bool f32 = e->dtype == FLOPE_DT_F32;
+  std::string s; double f = 0.0;
+  if (idx == 0) s = "prep_input|prep_input_kernel";
+  else if (idx == 1) { s = f32 ? "stem|naive_conv_kernel" : "stem|stem_mfma_kernel"; f = 2.0 * e->Hs * e->Ws * 64 * 147; }
+  else if (idx == 2) s = "maxpool|maxpool_kernel";
+  else if (idx < 3 + nc) {
+    const Conv& c = e->convs[idx - 3];
+    int BM, BN; tile_dims(c.cfg, &BM, &BN);
+    char k[96];
+    if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
+    else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s>", BM, BN, c.patch ? "patch" : "gather");
+    s = c.name + "|" + k;
+    f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
+  } else if (idx == 3 + nc) s = "avgpool|avgpool_kernel";
+  else if (idx == 4 + nc) { s = "fc1|fc1_kernel"; f = 2.0 * 512 * e->bod; }
+  else { s = "fc_rot+procrustes|fc2_procrustes_kernel"; f = 2.0 * 9 * e->bod; }
+  snprintf(name, name_cap, "%s", s.c_str());
+  *flops = f * batch;
+  return FLOPE_OK;
+}
 
 // plan introspection for DESIGN.md / tests: writes one line per conv into buf
 extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {

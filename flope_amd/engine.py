@@ -159,6 +159,26 @@ class PoseEngine:
     def launches(self) -> int:
         return int(self.lib.flope_forward_launches(self.handle))
 
+    def launch_info(self, batch: int):
+        """[(layer, kernel, flops)] for every launch of one forward."""
+        out = []
+        for i in range(self.launches()):
+            name = C.create_string_buffer(160)
+            fl = C.c_double()
+            _lib.check(self.lib.flope_launch_info(self.handle, i, batch, name, 160, C.byref(fl)), self.handle)
+            layer, kern = name.value.decode().split("|")
+            out.append((layer, kern, fl.value))
+        return out
+
+    def profile_read(self):
+        """per-launch GPU milliseconds of the last forward (needs set_option('profile', 1))."""
+        n = self.launches()
+        ms = (C.c_float * n)()
+        rc = self.lib.flope_profile_read(self.handle, ms, n)
+        if rc < 0:
+            _lib.check(rc, self.handle)
+        return [float(ms[i]) for i in range(rc)]
+
     def describe_plan(self) -> str:
         buf = C.create_string_buffer(8192)
         _lib.check(self.lib.flope_describe_plan(self.handle, buf, 8192), self.handle)

@@ -138,6 +138,12 @@ int flope_set_option(flope_handle h, const char* name, int value);
 double flope_forward_flops(flope_handle h, int batch);
 /* number of kernel launches flope_forward enqueues */
 int flope_forward_launches(flope_handle h);
+/* Profile mode (flope_set_option(h, "profile", 1)): flope_forward records a HIP event on the
+ * caller's stream before every launch and after the last.  flope_profile_read waits for the
+ * last event and writes the GPU time (ms) of each launch of the most recent forward; returns
+ * the number written or <0.  flope_launch_info: "layer|kernel" label and algorithmic FLOPs. */
+int flope_profile_read(flope_handle h, float* ms_out, int cap);
+int flope_launch_info(flope_handle h, int idx, int batch, char* name, int name_cap, double* flops);
 /* human-readable launch plan (one line per conv: tile config, patch/gather, LDS bytes) */
 int flope_describe_plan(flope_handle h, char* buf, int buflen);
 /* library / build identification */
