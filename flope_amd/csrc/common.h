@@ -74,6 +74,7 @@ struct ConvP {
   int per_image;       // 1: M tiles never straddle two images (tiles_per_image below)
   int tiles_per_image;
   int patch_rows_max;  // patch mode: LDS rows reserved
+  int dbg;             // timing experiments only: bit0 skip weight staging, bit1 skip pixel staging, bit2 skip MFMA
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

@@ -19,7 +19,7 @@
 
 // kernels (other translation units)
 extern "C" int flope_conv_mfma_init();
-extern "C" int flope_conv_mfma_launch(const ConvP* p, int dtype, int cfg, int patch, size_t lds, void* stream);
+extern "C" int flope_conv_mfma_launch(const ConvP* p, int dtype, int cfg, int patch, int nbuf, size_t lds, void* stream);
 extern "C" int flope_stem_init();
 extern "C" int flope_stem_launch(const StemP* p, int dtype, size_t lds, void* stream);
 extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream);
@@ -29,6 +29,9 @@ extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2,
 extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
+extern "C" int flope_stem_pool_init();
+extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
+                                      const void* w, const float* bias, void* out, int dtype, void* stream);
 
 using namespace flope_host;
 
@@ -47,7 +50,7 @@ struct Conv {
   int hin = 0, win = 0, hout = 0, wout = 0;   // unpadded
   int relu = 0;
   // plan
-  int cfg = 0, patch = 0, per_image = 0, tiles_per_image = 0, mtiles = 0, ntiles = 0, rows_max = 0;
+  int cfg = 0, patch = 0, nbuf = 2, per_image = 0, tiles_per_image = 0, mtiles = 0, ntiles = 0, rows_max = 0;
   size_t lds = 0;
   // device weights
   void* w_packed = nullptr;    // MFMA image (16-bit)
@@ -74,10 +77,13 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2;
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
   int ev_n = 0;
   int last_batch = 0;
+  bool last_fused = false;
   std::string err;
 };
 
@@ -144,22 +150,32 @@ void plan_conv(flope_engine* e, Conv& c) {
   const int B = e->maxB;
   const int HoWo = c.hout * c.wout;
   const int Wip = c.win + 2;
-  struct Cand { int cfg, patch, per_image, rows; size_t lds; };
+  struct Cand { int cfg, patch, per_image, rows, nbuf; size_t lds; };
   std::vector<Cand> cands;
   const bool can_patch = e->opt_patch && c.k == 3 && c.stride == 1;
   std::vector<int> cfgs;
   if (c.cout == 64) { if (e->opt_bm256) cfgs.push_back(2); cfgs.push_back(0); }
   else cfgs.push_back(1);
-  for (int cfg : cfgs) {
-    int BM, BN; tile_dims(cfg, &BM, &BN);
-    if (can_patch) {
-      for (int pi = 0; pi < 2; ++pi) {
-        const int rows = patch_rows(c, B, BM, pi != 0);
-        cands.push_back({cfg, 1, pi, rows, (size_t)2 * BN * 128 + (size_t)rows * Wip * 128});
-      }
+  // a 3-deep ring pays where the weight tile is 16 KB per step (Cout >= 128); for the 64-channel layers
+  // it would push the 256-pixel tile out of LDS and cost more than it hides (r01 layer timings)
+  std::vector<int> depths;
+  if (e->opt_nbuf == 3 && c.cout >= 128) depths.push_back(3);
+  depths.push_back(2);
+  // preference: deepest ring first, then patch before gather, flat tiles before per-image tiles
+  for (int nb : depths)
+    for (int cfg : cfgs) {
+      int BM, BN; tile_dims(cfg, &BM, &BN);
+      if (can_patch)
+        for (int pi = 0; pi < 2; ++pi) {
+          const int rows = patch_rows(c, B, BM, pi != 0);
+          cands.push_back({cfg, 1, pi, rows, nb, (size_t)nb * BN * 128 + (((size_t)rows * Wip * 128 + 4095) & ~(size_t)4095)});
+        }
     }
-    cands.push_back({cfg, 0, 0, 0, (size_t)2 * BN * 128 + (size_t)2 * BM * 128});
-  }
+  for (int nb : depths)
+    for (int cfg : cfgs) {
+      int BM, BN; tile_dims(cfg, &BM, &BN);
+      cands.push_back({cfg, 0, 0, 0, nb, (size_t)nb * BN * 128 + (size_t)nb * BM * 128});
+    }
   // first candidate that lets two workgroups share a CU; else the smallest that fits at all
   const Cand* pick = nullptr;
   for (const Cand& cd : cands)
@@ -168,17 +184,17 @@ void plan_conv(flope_engine* e, Conv& c) {
     for (const Cand& cd : cands)
       if (cd.lds <= kLdsMax && (!pick || cd.lds < pick->lds)) pick = &cd;
   int BM, BN; tile_dims(pick->cfg, &BM, &BN);
-  c.cfg = pick->cfg; c.patch = pick->patch; c.per_image = pick->per_image; c.rows_max = pick->rows; c.lds = pick->lds;
+  c.cfg = pick->cfg; c.patch = pick->patch; c.nbuf = pick->nbuf; c.per_image = pick->per_image; c.rows_max = pick->rows; c.lds = pick->lds;
   c.tiles_per_image = (HoWo + BM - 1) / BM;
   c.ntiles = c.cout / BN;
   (void)B;
 }
 
-void conv_params(const flope_engine* e, const Conv& c, int batch, ConvP* p) {
+void conv_params(const flope_engine* e, const std::vector<Buf>& bufs, const Conv& c, int batch, ConvP* p) {
   int BM, BN; tile_dims(c.cfg, &BM, &BN);
   memset(p, 0, sizeof(*p));
-  p->in = e->bufs[c.in_buf].ptr; p->out = e->bufs[c.out_buf].ptr;
-  p->res = c.res_buf >= 0 ? e->bufs[c.res_buf].ptr : nullptr;
+  p->in = bufs[c.in_buf].ptr; p->out = bufs[c.out_buf].ptr;
+  p->res = c.res_buf >= 0 ? bufs[c.res_buf].ptr : nullptr;
   p->w = c.w_packed; p->bias = c.bias;
   p->B = batch; p->Hip = c.hin + 2; p->Wip = c.win + 2; p->Cin = c.cin;
   p->Ho = c.hout; p->Wo = c.wout; p->Hop = c.hout + 2; p->Wop = c.wout + 2; p->Cout = c.cout;
@@ -186,7 +202,7 @@ void conv_params(const flope_engine* e, const Conv& c, int batch, ConvP* p) {
   p->M = batch * c.hout * c.wout; p->relu = c.relu; p->nchunks = c.cin / 64;
   p->per_image = c.per_image; p->tiles_per_image = c.tiles_per_image;
   p->mtiles = c.per_image ? batch * c.tiles_per_image : (p->M + BM - 1) / BM;
-  p->ntiles = c.ntiles; p->patch_rows_max = c.rows_max;
+  p->ntiles = c.ntiles; p->patch_rows_max = c.rows_max; p->dbg = e->opt_dbg;
 }
 
 template <typename V>
@@ -282,6 +298,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
   if (dtype != FLOPE_DT_F32) {
     int s = flope_conv_mfma_init();
     if (s == 0) s = flope_stem_init();
+    if (s == 0) s = flope_stem_pool_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
   const size_t B = (size_t)max_batch;
@@ -349,6 +366,11 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
   CREATE_TRY(hipMalloc((void**)&e->feat, B * 512 * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->hidden, B * (size_t)e->bod * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->r9_scratch, B * 9 * sizeof(float)));
+  for (int i = 0; i < 2; ++i) {
+    CREATE_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+  }
+  CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   e->ev.resize(e->convs.size() + 8);
   for (hipEvent_t& ev : e->ev) CREATE_TRY(hipEventCreate(&ev));
   CREATE_TRY(hipDeviceSynchronize());
@@ -367,6 +389,8 @@ extern "C" int flope_destroy(flope_handle e) {
   void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
+  for (int i = 0; i < 2; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
   delete e;
   return FLOPE_OK;
 }
@@ -376,6 +400,11 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   int prev;
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
+  else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value >= 2 ? 2 : 1; return prev; }
+  else if (!strcmp(name, "fuse_stem")) { prev = e->opt_fuse_stem; e->opt_fuse_stem = value != 0; return prev; }
+  else if (!strcmp(name, "ldspad")) { prev = e->opt_ldspad; e->opt_ldspad = value; return prev; }
+  else if (!strcmp(name, "dbg")) { prev = e->opt_dbg; e->opt_dbg = value; return prev; }
+  else if (!strcmp(name, "nbuf")) { prev = e->opt_nbuf; e->opt_nbuf = value == 2 ? 2 : 3; }
   else if (!strcmp(name, "profile")) { prev = e->opt_profile; e->opt_profile = value != 0; e->ev_n = 0; return prev; }
   else return fail(e, FLOPE_EINVAL, std::string("flope_set_option: unknown option ") + name);
   rebuild_plan(e);
@@ -430,60 +459,98 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
 }
 
 // trunk: crop batch -> last BasicBlock output + pooled features
+// One slice [start, start+batch) of the crop batch through the trunk + fc.0 on `stream`.  Every tensor is
+// batch-major, so a slice is just an offset view of the same buffers.
+static int run_slice(flope_engine* e, const void* x_dev, int in_format, int start, int batch, void* stream, bool marks) {
+  const int dt = e->dtype;
+  const size_t in_img_bytes = (size_t)e->H * e->W * 3 * (in_format == 0 ? 4 : (in_format == 3 ? 1 : 2));
+  const char* x = (const char*)x_dev + (size_t)start * in_img_bytes;
+  std::vector<Buf> vb = e->bufs;
+  for (Buf& b : vb) b.ptr = (char*)b.ptr + (size_t)start * (b.h + 2) * (b.w + 2) * b.C * e->esz;
+  char* stem_in = (char*)e->stem_in + (size_t)start * e->sHip * e->sWip * 4 * e->esz;
+  float* feat = e->feat + (size_t)start * 512;
+  float* hidden = e->hidden + (size_t)start * e->bod;
+#define SMARK() do { if (marks) MARK(e, stream); } while (0)
+  const Buf& bs = vb[e->stage_buf[FLOPE_STAGE_STEM]];
+  const Buf& bp = vb[e->stage_buf[FLOPE_STAGE_POOL]];
+  const bool fused = e->opt_fuse_stem && dt != FLOPE_DT_F32;
+  if (fused) {
+    SMARK();
+    K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w,
+                                                   e->stem_bias, bp.ptr, dt, stream));
+  } else {
+    SMARK();
+    K_TRY(e, "prep_input", flope_prep_input_launch(x, in_format, batch, e->H, e->W, stem_in, e->sHip, e->sWip, dt, stream));
+    if (dt == FLOPE_DT_F32) {
+      NaiveConvP p; memset(&p, 0, sizeof(p));
+      p.in = (const float*)stem_in; p.out = (float*)bs.ptr; p.w = e->stem_w_naive; p.bias = e->stem_bias;
+      p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Cin_stored = 4; p.Cin = 3; p.Ho = e->Hs; p.Wo = e->Ws;
+      p.Hop = e->Hs + 2; p.Wop = e->Ws + 2; p.Cout = 64; p.KH = 7; p.KW = 7; p.stride = 2; p.in_off = 0; p.relu = 1;
+      SMARK();
+      K_TRY(e, "stem (fp32)", flope_naive_conv_launch(&p, stream));
+    } else {
+      StemP p; memset(&p, 0, sizeof(p));
+      p.in = stem_in; p.out = bs.ptr; p.w = e->stem_w; p.bias = e->stem_bias;
+      p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Ho = e->Hs; p.Wo = e->Ws;
+      p.tiles_per_image = e->stem_tiles; p.patch_rows_max = e->stem_rows;
+      SMARK();
+      K_TRY(e, "stem", flope_stem_launch(&p, dt, e->stem_lds, stream));
+    }
+    PoolP pp; pp.in = bs.ptr; pp.out = bp.ptr; pp.B = batch; pp.Hip = bs.h + 2; pp.Wip = bs.w + 2; pp.C = 64; pp.Ho = bp.h; pp.Wo = bp.w;
+    SMARK();
+    K_TRY(e, "maxpool", flope_maxpool_launch(&pp, dt, stream));
+  }
+  for (const Conv& c : e->convs) {
+    if (dt == FLOPE_DT_F32) {
+      NaiveConvP p; memset(&p, 0, sizeof(p));
+      p.in = (const float*)vb[c.in_buf].ptr; p.out = (float*)vb[c.out_buf].ptr;
+      p.res = c.res_buf >= 0 ? (const float*)vb[c.res_buf].ptr : nullptr;
+      p.w = c.w_naive; p.bias = c.bias;
+      p.B = batch; p.Hip = c.hin + 2; p.Wip = c.win + 2; p.Cin_stored = c.cin; p.Cin = c.cin; p.Ho = c.hout; p.Wo = c.wout;
+      p.Hop = c.hout + 2; p.Wop = c.wout + 2; p.Cout = c.cout; p.KH = c.k; p.KW = c.k; p.stride = c.stride;
+      p.in_off = c.k == 3 ? 0 : 1; p.relu = c.relu;
+      SMARK();
+      K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
+    } else {
+      ConvP p; conv_params(e, vb, c, batch, &p);
+      SMARK();
+      K_TRY(e, c.name.c_str(), flope_conv_mfma_launch(&p, dt, c.cfg, c.patch, c.nbuf, c.lds + (size_t)e->opt_ldspad * 1024, stream));
+    }
+  }
+  const Buf& bl = vb[e->final_buf];
+  SMARK();
+  K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
+  SMARK();
+  K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->b1, hidden, batch, 512, e->bod, stream));
+#undef SMARK
+  return FLOPE_OK;
+}
+
+// trunk + fc.0 for the whole batch.  With the "streams" option (default 2) and a large enough batch the
+// crops are split into two halves that run the same launch sequence on two internal streams forked from /
+// joined to the caller's stream: the tail of one half's kernel (the last, partly filled round of
+// workgroups -- up to 24 % of a launch at B = 256) overlaps the head of the other half's.
 static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batch, void* stream) {
   if (!e->weights_loaded) return fail(e, FLOPE_ESTATE, "forward before flope_load_weights");
   if (!x_dev) return fail(e, FLOPE_EINVAL, "forward: x_dev is NULL");
   if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "forward: batch must be within 1..max_batch");
   if (in_format < 0 || in_format > 3) return fail(e, FLOPE_EINVAL, "forward: unknown input format");
-  const int dt = e->dtype;
   e->ev_n = 0;
-  MARK(e, stream);
-  K_TRY(e, "prep_input", flope_prep_input_launch(x_dev, in_format, batch, e->H, e->W, e->stem_in, e->sHip, e->sWip, dt, stream));
-  const Buf& bs = e->bufs[e->stage_buf[FLOPE_STAGE_STEM]];
-  const Buf& bp = e->bufs[e->stage_buf[FLOPE_STAGE_POOL]];
-  if (dt == FLOPE_DT_F32) {
-    NaiveConvP p; memset(&p, 0, sizeof(p));
-    p.in = (const float*)e->stem_in; p.out = (float*)bs.ptr; p.w = e->stem_w_naive; p.bias = e->stem_bias;
-    p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Cin_stored = 4; p.Cin = 3; p.Ho = e->Hs; p.Wo = e->Ws;
-    p.Hop = e->Hs + 2; p.Wop = e->Ws + 2; p.Cout = 64; p.KH = 7; p.KW = 7; p.stride = 2; p.in_off = 0; p.relu = 1;
-    MARK(e, stream);
-    K_TRY(e, "stem (fp32)", flope_naive_conv_launch(&p, stream));
-  } else {
-    StemP p; memset(&p, 0, sizeof(p));
-    p.in = e->stem_in; p.out = bs.ptr; p.w = e->stem_w; p.bias = e->stem_bias;
-    p.B = batch; p.Hip = e->sHip; p.Wip = e->sWip; p.Ho = e->Hs; p.Wo = e->Ws;
-    p.tiles_per_image = e->stem_tiles; p.patch_rows_max = e->stem_rows;
-    MARK(e, stream);
-    K_TRY(e, "stem", flope_stem_launch(&p, dt, e->stem_lds, stream));
-  }
-  {
-    PoolP p; p.in = bs.ptr; p.out = bp.ptr; p.B = batch; p.Hip = bs.h + 2; p.Wip = bs.w + 2; p.C = 64; p.Ho = bp.h; p.Wo = bp.w;
-    MARK(e, stream);
-    K_TRY(e, "maxpool", flope_maxpool_launch(&p, dt, stream));
-  }
-  for (const Conv& c : e->convs) {
-    if (dt == FLOPE_DT_F32) {
-      NaiveConvP p; memset(&p, 0, sizeof(p));
-      p.in = (const float*)e->bufs[c.in_buf].ptr; p.out = (float*)e->bufs[c.out_buf].ptr;
-      p.res = c.res_buf >= 0 ? (const float*)e->bufs[c.res_buf].ptr : nullptr;
-      p.w = c.w_naive; p.bias = c.bias;
-      p.B = batch; p.Hip = c.hin + 2; p.Wip = c.win + 2; p.Cin_stored = c.cin; p.Cin = c.cin; p.Ho = c.hout; p.Wo = c.wout;
-      p.Hop = c.hout + 2; p.Wop = c.wout + 2; p.Cout = c.cout; p.KH = c.k; p.KW = c.k; p.stride = c.stride;
-      p.in_off = c.k == 3 ? 0 : 1; p.relu = c.relu;
-      MARK(e, stream);
-      K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
-    } else {
-      ConvP p; conv_params(e, c, batch, &p);
-      MARK(e, stream);
-      K_TRY(e, c.name.c_str(), flope_conv_mfma_launch(&p, dt, c.cfg, c.patch, c.lds, stream));
-    }
-  }
-  const Buf& bl = e->bufs[e->final_buf];
-  MARK(e, stream);
-  K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, e->feat, batch, bl.h, bl.w, 512, dt, stream));
-  MARK(e, stream);
-  K_TRY(e, "fc1", flope_fc1_launch(e->feat, e->W1, e->b1, e->hidden, batch, 512, e->bod, stream));
+  e->last_fused = e->opt_fuse_stem && e->dtype != FLOPE_DT_F32;
   e->last_batch = batch;
+  const int ns = (e->opt_streams >= 2 && !e->opt_profile && batch >= 64) ? 2 : 1;
+  if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true);
+  hipStream_t user = (hipStream_t)stream;
+  HIP_TRY(e, hipEventRecord(e->ev_fork, user));
+  const int half = (batch + 1) / 2;
+  for (int s = 0; s < 2; ++s) {
+    HIP_TRY(e, hipStreamWaitEvent(e->side[s], e->ev_fork, 0));
+    const int start = s == 0 ? 0 : half, cnt = s == 0 ? half : batch - half;
+    int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false);
+    if (rc) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev_join[s], e->side[s]));
+  }
+  for (int s = 0; s < 2; ++s) HIP_TRY(e, hipStreamWaitEvent(user, e->ev_join[s], 0));
   return FLOPE_OK;
 }
 
@@ -520,6 +587,8 @@ extern "C" int flope_read_stage(flope_handle e, int stage, int batch, float* dst
     return FLOPE_OK;
   }
   if (stage < 0 || stage > 9) return fail(e, FLOPE_EINVAL, "flope_read_stage: unknown stage");
+  if (stage == FLOPE_STAGE_STEM && e->last_fused)
+    return fail(e, FLOPE_ESTATE, "flope_read_stage: the stem activation is not materialised by the fused stem+maxpool kernel (set option fuse_stem=0)");
   const Buf& b = e->bufs[e->stage_buf[stage]];
   dims_out[0] = batch; dims_out[1] = b.C; dims_out[2] = b.h; dims_out[3] = b.w;
   K_TRY(e, "read_stage", flope_read_stage_launch(b.ptr, dst_dev, batch, b.C, b.h, b.w, e->dtype, stream));
@@ -534,7 +603,8 @@ extern "C" double flope_forward_flops(flope_handle e, int batch) {
   return 2.0 * macs * batch;
 }
 
-extern "C" int flope_forward_launches(flope_handle e) { return e ? (int)e->convs.size() + 6 : 0; }
+static int head_launches(const flope_engine* e) { return (e->opt_fuse_stem && e->dtype != FLOPE_DT_F32) ? 1 : 3; }
+extern "C" int flope_forward_launches(flope_handle e) { return e ? (int)e->convs.size() + 3 + head_launches(e) : 0; }
 
 // profile mode ("profile" option): per-launch GPU time of the LAST flope_forward, from HIP
 // events recorded on the caller's stream around every launch.  Synchronises on the last event.
@@ -551,18 +621,25 @@ extern "C" int flope_profile_read(flope_handle e, float* ms_out, int cap) {
 extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name, int name_cap, double* flops) {
   if (!e || !name || name_cap < 1 || !flops) return fail(e, FLOPE_EINVAL, "flope_launch_info: NULL argument");
   const int nc = (int)e->convs.size();
-  if (idx < 0 || idx >= nc + 6) return fail(e, FLOPE_EINVAL, "flope_launch_info: bad index");
+  const int nh = head_launches(e);
+  if (idx < 0 || idx >= nc + 3 + nh) return fail(e, FLOPE_EINVAL, "flope_launch_info: bad index");
   const bool f32 = e->dtype == FLOPE_DT_F32;
   std::string s; double f = 0.0;
-  if (idx == 0) s = "prep_input|prep_input_kernel";
-  else if (idx == 1) { s = f32 ? "stem|naive_conv_kernel" : "stem|stem_mfma_kernel"; f = 2.0 * e->Hs * e->Ws * 64 * 147; }
-  else if (idx == 2) s = "maxpool|maxpool_kernel";
+  if (nh == 1) {
+    if (idx == 0) { s = "input+stem+maxpool|stem_pool_kernel"; f = 2.0 * e->Hs * e->Ws * 64 * 147; }
+  } else {
+    if (idx == 0) s = "prep_input|prep_input_kernel";
+    else if (idx == 1) { s = f32 ? "stem|naive_conv_kernel" : "stem|stem_mfma_kernel"; f = 2.0 * e->Hs * e->Ws * 64 * 147; }
+    else if (idx == 2) s = "maxpool|maxpool_kernel";
+  }
+  idx += 3 - nh;
+  if (idx < 3) { /* named above */ }
   else if (idx < 3 + nc) {
     const Conv& c = e->convs[idx - 3];
     int BM, BN; tile_dims(c.cfg, &BM, &BN);
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
-    else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s>", BM, BN, c.patch ? "patch" : "gather");
+    else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
   } else if (idx == 3 + nc) s = "avgpool|avgpool_kernel";
@@ -581,8 +658,8 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
   snprintf(line, sizeof line, "stem: tiles/img=%d rows=%d lds=%zu\n", e->stem_tiles, e->stem_rows, e->stem_lds);
   s += line;
   for (const Conv& c : e->convs) {
-    snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
-             c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.per_image, c.rows_max, c.lds);
+    snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
+             c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);
     s += line;
   }
   snprintf(buf, buflen, "%s", s.c_str());

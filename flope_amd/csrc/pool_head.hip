@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ feat
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int k0 = 0; k0 < K; k0 += 16) {
     const f32x4 a = *(const f32x4*)(wrow + k0);
     f32x4 bv[4];

@@ -15,7 +15,7 @@
 // symmetric 4x4 N below; q is the eigenvector of the largest eigenvalue (cyclic
 // Jacobi in fp64).  No SVD, no sign fix-up, det(R) = +1 by construction.  Undefined
 // exactly where the reference is (repeated top eigenvalue <=> sigma2 + sigma3 = 0).
-FLOPE_HD inline void procrustes3x3(const float* M, float* R) {
+FLOPE_HD inline void procrustes3x3_jacobi(const float* M, float* R) {
   double A[4][4], V[4][4];
   const double m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[3], m11 = M[4], m12 = M[5], m20 = M[6], m21 = M[7],
                m22 = M[8];
@@ -62,6 +62,90 @@ FLOPE_HD inline void procrustes3x3(const float* M, float* R) {
   R[0] = (float)(1.0 - 2.0 * (y * y + z * z));  R[1] = (float)(2.0 * (x * y - z * w));  R[2] = (float)(2.0 * (x * z + y * w));
   R[3] = (float)(2.0 * (x * y + z * w));  R[4] = (float)(1.0 - 2.0 * (x * x + z * z));  R[5] = (float)(2.0 * (y * z - x * w));
   R[6] = (float)(2.0 * (x * z - y * w));  R[7] = (float)(2.0 * (y * z + x * w));  R[8] = (float)(1.0 - 2.0 * (x * x + y * y));
+}
+
+// Fast path of the same eigenproblem (the Jacobi solve above costs ~40 us of serial fp64 per
+// launch): N is traceless, so its characteristic polynomial is
+//     P(l) = l^4 - 2|M|_F^2 l^2 - 8 det(M) l + det(N),
+// all roots real, the largest one l* = s1 + s2 + sign(det M) s3 <= sqrt(3)|M|_F.  Newton from that
+// upper bound converges monotonically (fp32 steps to get close, fp64 steps to finish); the
+// eigenvector is the best-conditioned column of adj(N - l* I) (rank-3 matrix => adj = c q q^T).
+// Returns false (caller falls back to Jacobi) when the top eigenvalue is not safely isolated.
+FLOPE_HD inline double det3(double a, double b, double c, double d, double e, double f, double g, double h, double i) {
+  return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
+
+FLOPE_HD inline bool procrustes3x3_newton(const float* M, float* R) {
+  double m[9], fro2 = 0.0;
+  for (int i = 0; i < 9; ++i) { m[i] = M[i]; fro2 += m[i] * m[i]; }
+  if (!(fro2 > 1e-60) || !(fro2 < 1e60)) return false;
+  const double inv = 1.0 / sqrt(fro2);               // the rotation is scale invariant: work with |M|_F = 1
+  for (int i = 0; i < 9; ++i) m[i] *= inv;
+  double n[4][4];
+  n[0][0] = m[0] + m[4] + m[8];  n[1][1] = m[0] - m[4] - m[8];  n[2][2] = -m[0] + m[4] - m[8];  n[3][3] = -m[0] - m[4] + m[8];
+  n[0][1] = n[1][0] = m[7] - m[5];  n[0][2] = n[2][0] = m[2] - m[6];  n[0][3] = n[3][0] = m[3] - m[1];
+  n[1][2] = n[2][1] = m[1] + m[3];  n[1][3] = n[3][1] = m[2] + m[6];  n[2][3] = n[3][2] = m[5] + m[7];
+  const double detM = det3(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]);
+  const double c2 = -2.0, c1 = -8.0 * detM;
+  const double c0 =
+      n[0][0] * det3(n[1][1], n[1][2], n[1][3], n[2][1], n[2][2], n[2][3], n[3][1], n[3][2], n[3][3]) -
+      n[0][1] * det3(n[1][0], n[1][2], n[1][3], n[2][0], n[2][2], n[2][3], n[3][0], n[3][2], n[3][3]) +
+      n[0][2] * det3(n[1][0], n[1][1], n[1][3], n[2][0], n[2][1], n[2][3], n[3][0], n[3][1], n[3][3]) -
+      n[0][3] * det3(n[1][0], n[1][1], n[1][2], n[2][0], n[2][1], n[2][2], n[3][0], n[3][1], n[3][2]);
+  float lf = 1.7320509f, c1f = (float)c1, c0f = (float)c0;
+  for (int it = 0; it < 10; ++it) {
+    const float l2 = lf * lf;
+    const float pv = (l2 - 2.f) * l2 + c1f * lf + c0f, dv = (4.f * l2 - 4.f) * lf + c1f;
+    if (!(dv > 1e-6f)) break;
+    lf -= pv / dv;
+  }
+  double l = (double)lf * (1.0 + 1e-6) + 1e-9;        // stay on the upper side for the monotone fp64 polish
+  bool ok = false;
+  for (int it = 0; it < 8; ++it) {
+    const double l2 = l * l;
+    const double pv = (l2 + c2) * l2 + c1 * l + c0, dv = (4.0 * l2 + 2.0 * c2) * l + c1;
+    if (!(dv > 1e-9)) return false;                    // top eigenvalue (nearly) repeated: gauge-degenerate input
+    const double dl = pv / dv;
+    l -= dl;
+    if (fabs(dl) <= 4e-16 * l) { ok = true; break; }
+  }
+  if (!ok) return false;
+  for (int i = 0; i < 4; ++i) n[i][i] -= l;
+  // diagonal cofactors of the rank-3 matrix: pick the row with the largest one
+  const double d0 = det3(n[1][1], n[1][2], n[1][3], n[2][1], n[2][2], n[2][3], n[3][1], n[3][2], n[3][3]);
+  const double d1 = det3(n[0][0], n[0][2], n[0][3], n[2][0], n[2][2], n[2][3], n[3][0], n[3][2], n[3][3]);
+  const double d2 = det3(n[0][0], n[0][1], n[0][3], n[1][0], n[1][1], n[1][3], n[3][0], n[3][1], n[3][3]);
+  const double d3 = det3(n[0][0], n[0][1], n[0][2], n[1][0], n[1][1], n[1][2], n[2][0], n[2][1], n[2][2]);
+  int r = 0; double best = fabs(d0);
+  if (fabs(d1) > best) { best = fabs(d1); r = 1; }
+  if (fabs(d2) > best) { best = fabs(d2); r = 2; }
+  if (fabs(d3) > best) { best = fabs(d3); r = 3; }
+  if (!(best > 1e-7)) return false;                    // eigen-gap too small for the adjugate to be trustworthy
+  // cofactor row r of (N - l I): q_j = (-1)^(r+j) minor(r, j)
+  double q[4];
+  for (int j = 0; j < 4; ++j) {
+    double s[9]; int t = 0;
+    for (int a = 0; a < 4; ++a) {
+      if (a == r) continue;
+      for (int b = 0; b < 4; ++b) {
+        if (b == j) continue;
+        s[t++] = n[a][b];
+      }
+    }
+    const double mn = det3(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+    q[j] = ((r + j) & 1) ? -mn : mn;
+  }
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double nn = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+  w *= nn; x *= nn; y *= nn; z *= nn;
+  R[0] = (float)(1.0 - 2.0 * (y * y + z * z));  R[1] = (float)(2.0 * (x * y - z * w));  R[2] = (float)(2.0 * (x * z + y * w));
+  R[3] = (float)(2.0 * (x * y + z * w));  R[4] = (float)(1.0 - 2.0 * (x * x + z * z));  R[5] = (float)(2.0 * (y * z - x * w));
+  R[6] = (float)(2.0 * (x * z - y * w));  R[7] = (float)(2.0 * (y * z + x * w));  R[8] = (float)(1.0 - 2.0 * (x * x + y * y));
+  return true;
+}
+
+FLOPE_HD inline void procrustes3x3(const float* M, float* R) {
+  if (!procrustes3x3_newton(M, R)) procrustes3x3_jacobi(M, R);
 }
 
 // nullify_yaw (mvg.py:240-251 with scipy extrinsic 'zyx'): zeroing the first Euler angle

@@ -1,0 +1,228 @@
+// Fused front of the trunk: crop batch (any FLOPE_IN_* format) -> Conv2d(3,64,k7,s2,p3) + folded
+// BatchNorm + ReLU -> MaxPool2d(k3,s2,p1) -> zero-bordered NHWC [B][Hq+2][Wq+2][64].
+// Reference call site: sunflower/models/posenet.py:25 -> torchvision ResNet._forward_impl
+// (conv1, bn1, relu, maxpool).
+//
+// Why fused: unfused, the 112x112x64 stem activation is written (205 MB at B=256) and read back
+// by the pool, and a separate pass converts the input -- ~450 MB of HBM traffic and two launch
+// boundaries around a kernel whose real output is 51 MB.  Here one workgroup owns an 8x8 tile of
+// POOLED pixels: it converts the 39x40 input window it needs straight from the caller's tensor
+// into LDS (4-channel pixels, zero outside the image), runs the 17x17 conv outputs that feed its
+// pool windows on MFMA (K = 7 kernel rows x [8 px x 4 ch]; see stem.hip), parks them post-ReLU in
+// LDS (aliasing the weight/input staging), max-pools there and writes 16-byte NHWC vectors.
+// The one-pixel conv halo is recomputed by the neighbour tile (289 conv px per 256 consumed).
+#include "common.h"
+
+#define GLDS16(gptr, lptr)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),          \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+struct StemPoolP {
+  const void* x;       // crop batch in in_format
+  void* out;           // padded NHWC [B][Hq+2][Wq+2][64]
+  const void* w;       // packed [7 ky][64 rows][32 k] LDS image (host_pack.h pack_stem)
+  const float* bias;   // [64]
+  int in_format;       // FLOPE_IN_*
+  int B, H, W;         // crop size
+  int Hs, Ws;          // conv output size
+  int Hq, Wq;          // pooled output size
+  int tiles_y, tiles_x;
+};
+
+template <typename T> __device__ __forceinline__ u32x2 pack4(float a, float b, float c) {
+  return u32x2{pack2<T>(a, b), pack2<T>(c, 0.f)};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int W_BYTES = 7 * 64 * 64;            // 28672
+  constexpr int PR = 39, PC = 40;                 // input window (rows x cols), 8 B per pixel
+  constexpr int P_BYTES = ((PR * PC * 8 + 15) / 16) * 16;
+  constexpr int CR = 17;                          // conv region is CR x CR
+  constexpr int NQ = CR * CR;                     // 289 conv pixels -> 19 MFMA pixel tiles
+  constexpr int MT = 5, NT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ws = smem;
+  char* const Ps = smem + W_BYTES;
+  char* const Cs = smem;                          // [NQ][64 ch] conv outputs, aliases Ws|Ps after the MFMA phase
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = lid % p.tiles_x; lid /= p.tiles_x;
+  const int ty = lid % p.tiles_y;
+  const int img = lid / p.tiles_y;
+  const int cr0 = 2 * (ty * 8) - 1, cc0 = 2 * (tx * 8) - 1;       // conv coords of region (0,0)
+  const int py0 = 2 * cr0 - 3, px0 = 2 * cc0 - 3;                  // input coords of window (0,0)
+
+  // ---- weights: linear LDS-DMA copy (28 pieces of 1 KiB; wave w moves pieces w, w+4, ...)
+  for (int i = wave; i < W_BYTES / 1024; i += 4) GLDS16((const char*)p.w + i * 1024 + lane * 16, Ws + i * 1024);
+
+  // ---- input window: convert from the caller's layout, zero outside the image.  All loads of a
+  // thread are issued before the first conversion (7 x 3 independent loads in flight) -- a
+  // load->convert->store loop exposes the HBM latency once per iteration.
+  {
+    constexpr int NI = (PR * PC + 255) / 256;                 // 7
+    float v0[NI], v1[NI], v2[NI];
+    size_t off[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = tid + k * 256;
+      const int r = i / PC, c = i - r * PC;
+      const int y = py0 + r, x = px0 + c;
+      ok[k] = i < PR * PC && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);   // always a legal address
+      off[k] = p.in_format == 0 ? ((size_t)img * 3 * p.H + yc) * p.W + xc : (((size_t)img * p.H + yc) * p.W + xc) * 3;
+    }
+    if (p.in_format == 0) {
+      const float* s = (const float*)p.x;
+      const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) { v0[k] = s[off[k]]; v1[k] = s[off[k] + plane]; v2[k] = s[off[k] + 2 * plane]; }
+    } else if (p.in_format == 3) {
+      const unsigned char* s = (const unsigned char*)p.x;
+      unsigned char a[NI], b[NI], c[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; c[k] = s[off[k] + 2]; }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) { v0[k] = (float)a[k] / 255.0f; v1[k] = (float)b[k] / 255.0f; v2[k] = (float)c[k] / 255.0f; }
+    } else {
+      const unsigned short* s = (const unsigned short*)p.x;
+      unsigned short a[NI], b[NI], c[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; c[k] = s[off[k] + 2]; }
+      if (p.in_format == 1) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          v0[k] = to_f32(__builtin_bit_cast(bf16_t, a[k])); v1[k] = to_f32(__builtin_bit_cast(bf16_t, b[k]));
+          v2[k] = to_f32(__builtin_bit_cast(bf16_t, c[k]));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          v0[k] = to_f32(__builtin_bit_cast(f16_t, a[k])); v1[k] = to_f32(__builtin_bit_cast(f16_t, b[k]));
+          v2[k] = to_f32(__builtin_bit_cast(f16_t, c[k]));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = tid + k * 256;
+      if (i < PR * PC) *(u32x2*)(Ps + i * 8) = ok[k] ? pack4<T>(v0[k], v1[k], v2[k]) : u32x2{0u, 0u};
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- MFMA: wave w owns pixel tiles 5w .. 5w+4 (tile 19 does not exist: clamped, never stored)
+  int xo[MT];
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    const int q = min((wave * MT + pt) * 16 + r16, NQ - 1);
+    const int qr = q / CR, qc = q - qr * CR;
+    xo[pt] = (2 * qr * PC + 2 * qc) * 8 + g * 16;
+  }
+  const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;       // 64-byte weight rows: slot g at g ^ h[(r>>2)&3]
+  const int wo_ = r16 * 64 + ((g ^ wsw) << 4);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+    frag wf[NT], xf[MT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(Ws + ky * 4096 + ct * 1024 + wo_);
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) xf[pt] = *(const frag*)(Ps + xo[pt] + ky * (PC * 8));
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], acc[pt][ct]);
+  }
+  __syncthreads();                                          // everyone is done reading Ws / Ps
+
+  // ---- bias + ReLU -> Cs (positions outside the conv output are 0: neutral for a max of ReLU values)
+  {
+    float bias[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias[i] = p.bias[g * 16 + i];
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) {
+      const int q = (wave * MT + pt) * 16 + r16;
+      if (q < NQ) {
+        const int qr = q / CR, qc = q - qr * CR;
+        const int cr = cr0 + qr, cc = cc0 + qc;
+        const bool inside = cr >= 0 && cr < p.Hs && cc >= 0 && cc < p.Ws;
+        u32x4 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) {
+            const int c = h * 8 + w2 * 2;                   // channel pair c, c+1 of this lane's 16
+            const float v0 = inside ? fmaxf(acc[pt][c >> 2][c & 3] + bias[c], 0.f) : 0.f;
+            const float v1 = inside ? fmaxf(acc[pt][(c + 1) >> 2][(c + 1) & 3] + bias[c + 1], 0.f) : 0.f;
+            o[h][w2] = pack2<T>(v0, v1);
+          }
+        // row q, 16-byte slots 2g and 2g+1, stored at slot ^ (q & 7)
+        *(u32x4*)(Cs + q * 128 + (((2 * g) ^ (q & 7)) << 4)) = o[0];
+        *(u32x4*)(Cs + q * 128 + (((2 * g + 1) ^ (q & 7)) << 4)) = o[1];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3x3 / s2 max-pool out of LDS: item = (pooled pixel, 8-channel group)
+  for (int i = tid; i < 64 * 8; i += 256) {
+    const int cg = i & 7, pp = i >> 3;
+    const int pr = pp >> 3, pc = pp & 7;
+    const int oy = ty * 8 + pr, ox = tx * 8 + pc;
+    if (oy >= p.Hq || ox >= p.Wq) continue;
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int q = (2 * pr + dy) * CR + 2 * pc + dx;
+        const u32x4 v = *(const u32x4*)(Cs + q * 128 + ((cg ^ (q & 7)) << 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m[2 * k] = fmaxf(m[2 * k], unpack_lo<T>(v[k]));
+          m[2 * k + 1] = fmaxf(m[2 * k + 1], unpack_hi<T>(v[k]));
+        }
+      }
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack2<T>(m[2 * k], m[2 * k + 1]);
+    char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
+    *(u32x4*)dst = o;
+  }
+}
+
+extern "C" size_t flope_stem_pool_lds() { return 7 * 64 * 64 + ((39 * 40 * 8 + 15) / 16) * 16; }
+
+extern "C" int flope_stem_pool_init() {
+  hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)stem_pool_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  return (int)e;
+}
+
+extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq,
+                                      int Wq, const void* w, const float* bias, void* out, int dtype, void* stream) {
+  StemPoolP p;
+  p.x = x; p.out = out; p.w = w; p.bias = bias; p.in_format = in_format;
+  p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws_; p.Hq = Hq; p.Wq = Wq;
+  p.tiles_y = (Hq + 7) / 8; p.tiles_x = (Wq + 7) / 8;
+  const dim3 grid(B * p.tiles_y * p.tiles_x), block(256);
+  const size_t lds = flope_stem_pool_lds();
+  if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, grid, block, lds, (hipStream_t)stream, p);
+  else            hipLaunchKernelGGL(stem_pool_kernel<f16_t>, grid, block, lds, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}

@@ -10,6 +10,18 @@ void hh_procrustes(const float* M, float* R, int n) {
   for (int i = 0; i < n; ++i) procrustes3x3(M + 9 * i, R + 9 * i);
 }
 
+void hh_procrustes_jacobi(const float* M, float* R, int n) {
+  for (int i = 0; i < n; ++i) procrustes3x3_jacobi(M + 9 * i, R + 9 * i);
+}
+
+// returns how many inputs took the Newton fast path
+int hh_procrustes_newton_count(const float* M, int n) {
+  int c = 0;
+  float R[9];
+  for (int i = 0; i < n; ++i) c += procrustes3x3_newton(M + 9 * i, R) ? 1 : 0;
+  return c;
+}
+
 void hh_nullify_yaw(const float* R, float* O, int n) {
   for (int i = 0; i < n; ++i) nullify_yaw3x3(R + 9 * i, O + 9 * i);
 }

@@ -76,6 +76,39 @@ def test_horn_procrustes_matches_svd_oracle(harness):
     np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-5)
 
 
+def test_procrustes_fast_path_and_fallback(harness):
+    """Newton/adjugate fast path == Jacobi == SVD oracle; degenerate inputs take the Jacobi fallback."""
+    g = torch.Generator().manual_seed(8)
+    M = torch.randn(4096, 3, 3, generator=g) * torch.logspace(-6, 6, 4096)[:, None, None]     # scale invariance
+    Mn = np.ascontiguousarray(M.numpy().reshape(-1, 9))
+    a, b = np.empty_like(Mn), np.empty_like(Mn)
+    harness.hh_procrustes(_f(Mn), _f(a), Mn.shape[0])
+    harness.hh_procrustes_jacobi(_f(Mn), _f(b), Mn.shape[0])
+    sv = O.singular_values(M).numpy()
+    well = (sv[:, 1] + sv[:, 2]) / sv[:, 0] > 0.05
+    ref = O.special_procrustes(M.double()).numpy().reshape(-1, 9)
+    np.testing.assert_allclose(a[well], ref[well], atol=2e-5)
+    np.testing.assert_allclose(a[well], b[well], atol=2e-5)
+    assert harness.hh_procrustes_newton_count(_f(Mn), Mn.shape[0]) > 0.95 * Mn.shape[0]
+    # rotations, scaled rotations, reflections, rank-deficient and zero inputs
+    from scipy.spatial.transform import Rotation
+    Rr = Rotation.random(64, random_state=2).as_matrix().astype(np.float32)
+    special = np.concatenate([Rr, 3.5 * Rr, Rr * np.array([1, 1, -1], np.float32)[None, None, :],
+                              np.zeros((1, 3, 3), np.float32), np.ones((1, 3, 3), np.float32),
+                              np.diag([1, 1, 0]).astype(np.float32)[None], np.diag([2, 0, 0]).astype(np.float32)[None]])
+    sp = np.ascontiguousarray(special.reshape(-1, 9))
+    out = np.empty_like(sp)
+    harness.hh_procrustes(_f(sp), _f(out), sp.shape[0])
+    np.testing.assert_allclose(out[:64], Rr.reshape(-1, 9), atol=2e-6)
+    np.testing.assert_allclose(out[64:128], Rr.reshape(-1, 9), atol=2e-6)
+    Ro = out.reshape(-1, 3, 3).astype(np.float64)
+    assert np.all(np.isfinite(Ro))
+    np.testing.assert_allclose(np.linalg.det(Ro), 1.0, atol=1e-5)
+    np.testing.assert_allclose(Ro @ Ro.transpose(0, 2, 1), np.tile(np.eye(3), (len(Ro), 1, 1)), atol=1e-5)
+    ref = O.special_procrustes(torch.from_numpy(special[128:192]).double()).numpy()
+    np.testing.assert_allclose(Ro[128:192], ref, atol=2e-5)                                  # reflections: det fixed to +1
+
+
 def test_nullify_yaw_matches_scipy_oracle(harness):
     from scipy.spatial.transform import Rotation
     R = Rotation.random(256, random_state=4).as_matrix().astype(np.float32).reshape(-1, 9)

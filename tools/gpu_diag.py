@@ -32,6 +32,8 @@ def parity(sd, H, W, B, dtype, opts):
     torch.cuda.synchronize()
     line = []
     for s in STAGES:
+        if s == "stem" and dtype != "f32" and opts.get("fuse_stem", 1):
+            continue
         got = e.read_stage(s, B).cpu()
         line.append(f"{s}={rel(got, ref[s]):.1e}")
     line.append(f"r9={rel(r9.cpu(), ref['r9']):.1e}")
@@ -75,12 +77,14 @@ def main():
     sd = synthetic_state_dict(0)
     e = PoseEngine(224, 224, 256, "f16"); print(e.describe_plan()); e.close()
     safe(parity, sd, 96, 80, 3, "f32", {})
+    for hw in ((224, 224, 5), (65, 71, 2), (130, 50, 3)):
+        safe(parity, sd, hw[0], hw[1], hw[2], "f16", dict(fuse_stem=1))
     for dtype in ("f16", "bf16"):
-        for opts in (dict(patch=0, bm256=0), dict(patch=1, bm256=1), dict(patch=1, bm256=0), dict(patch=0, bm256=1)):
+        for opts in [dict(patch=a, bm256=b, nbuf=c, fuse_stem=a) for a in (0, 1) for b in (0, 1) for c in (2, 3)]:
             safe(parity, sd, 96, 80, 3, dtype, opts)
             if not quick:
                 safe(parity, sd, 224, 224, 5, dtype, opts)
-    for opts in (dict(patch=0, bm256=0), dict(patch=0, bm256=1), dict(patch=1, bm256=0), dict(patch=1, bm256=1)):
+    for opts in [dict(streams=1), dict(streams=2), dict(streams=2, nbuf=3), dict(streams=1, fuse_stem=0)]:
         safe(timing, sd, 224, 224, 256, "f16", opts)
     safe(timing, sd, 224, 224, 256, "bf16", dict(patch=1, bm256=1))
     safe(timing, sd, 512, 512, 64, "f16", dict(patch=1, bm256=1), iters=5)
