@@ -35,7 +35,17 @@ def cpu_baseline(crop: int, budget_s: float = 15.0):
     """Oracle forward + Procrustes on the host cores, B = 16."""
     from flope_amd.weights import synthetic_state_dict
     from oracle import posenet_ref as O
-    threads = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count: affinity mask, then the cgroup quota, and never more
+    # than 16 threads when neither narrows it down (a 1-GPU box owns 16 of the host's cores)
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = min(threads, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if threads > 32:
+        threads = 16
     torch.set_num_threads(threads)
     sd = synthetic_state_dict(0)
     torch.manual_seed(0)

@@ -37,7 +37,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   typedef typename Elem<T>::frag frag;
   constexpr int W_BYTES = 7 * 64 * 64;            // 28672
-  constexpr int PR = 39, PC = 40;                 // input window (rows x cols), 8 B per pixel
+  constexpr int PR = 39, PC = 42;                 // input window rows x (40 used + 2 pad) cols, 8 B per pixel;
+                                                  // the 21-slot row pitch keeps the column tiles at <= 2-way conflicts
   constexpr int P_BYTES = ((PR * PC * 8 + 15) / 16) * 16;
   constexpr int CR = 17;                          // conv region is CR x CR
   constexpr int NQ = CR * CR;                     // 289 conv pixels -> 19 MFMA pixel tiles
@@ -117,12 +118,18 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- MFMA: wave w owns pixel tiles 5w .. 5w+4 (tile 19 does not exist: clamped, never stored)
-  int xo[MT];
+  // ---- MFMA: wave w owns pixel tiles 5w .. 5w+4 of the 19 that cover the 17x17 conv region:
+  // tile t < 17 = conv row t, columns 0..15 (16 consecutive 16-byte windows: conflict-free reads);
+  // tile 17 = column 16 of rows 0..15; tile 18 = the corner (16,16).  Tile 19 does not exist.
+  int xo[MT], qidx[MT];
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) {
-    const int q = min((wave * MT + pt) * 16 + r16, NQ - 1);
-    const int qr = q / CR, qc = q - qr * CR;
+    const int t = wave * MT + pt;
+    int qr, qc;
+    if (t < CR) { qr = t; qc = r16; }
+    else if (t == CR) { qr = r16; qc = CR - 1; }
+    else { qr = CR - 1; qc = CR - 1; }
+    qidx[pt] = (t < CR + 1 || (t == CR + 1 && r16 == 0)) ? qr * CR + qc : -1;
     xo[pt] = (2 * qr * PC + 2 * qc) * 8 + g * 16;
   }
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;       // 64-byte weight rows: slot g at g ^ h[(r>>2)&3]
@@ -153,8 +160,8 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
     for (int i = 0; i < 16; ++i) bias[i] = p.bias[g * 16 + i];
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
-      const int q = (wave * MT + pt) * 16 + r16;
-      if (q < NQ) {
+      const int q = qidx[pt];
+      if (q >= 0) {
         const int qr = q / CR, qc = q - qr * CR;
         const int cr = cr0 + qr, cc = cc0 + qc;
         const bool inside = cr >= 0 && cr < p.Hs && cc >= 0 && cc < p.Ws;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   }
 }
 
-extern "C" size_t flope_stem_pool_lds() { return 7 * 64 * 64 + ((39 * 40 * 8 + 15) / 16) * 16; }
+extern "C" size_t flope_stem_pool_lds() { return 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16; }
 
 extern "C" int flope_stem_pool_init() {
   hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
