@@ -29,6 +29,8 @@ extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2,
 extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
+extern "C" int flope_conv_stag_init();
+extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, size_t lds, void* stream);
 extern "C" int flope_stem_pool_init();
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
                                       const void* w, const float* bias, void* out, int dtype, void* stream);
@@ -54,6 +56,8 @@ struct Conv {
   size_t lds = 0;
   // device weights
   void* w_packed = nullptr;    // MFMA image (16-bit)
+  void* w_stag = nullptr;      // conv_stag image (16-bit), 3x3 s1 Cout >= 128 only
+  int stag = 0, stag_patch_bytes = 0; size_t stag_lds = 0;
   float* w_naive = nullptr;    // [ky][kx][ci][cout]
   float* bias = nullptr;
 };
@@ -77,9 +81,9 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2;
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_stag = 1;
+  hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
   int ev_n = 0;
   int last_batch = 0;
@@ -187,7 +191,17 @@ void plan_conv(flope_engine* e, Conv& c) {
   c.cfg = pick->cfg; c.patch = pick->patch; c.nbuf = pick->nbuf; c.per_image = pick->per_image; c.rows_max = pick->rows; c.lds = pick->lds;
   c.tiles_per_image = (HoWo + BM - 1) / BM;
   c.ntiles = c.cout / BN;
-  (void)B;
+  // second-generation kernel (conv_stag.hip): 256 x 128 tiles, 32-channel steps, double-buffered patch
+  c.stag = 0;
+  if (e->opt_stag && c.k == 3 && c.stride == 1 && c.cout >= 128 && c.cin % 32 == 0 && c.cin >= 64) {
+    const int rows = patch_rows(c, B, 256, false);
+    const long pieces = (long)rows * Wip * 4;
+    int P = (int)((pieces + 511) / 512);
+    P = (P + 1) & ~1;                                  // kernel instantiations: 2, 4, 6, 8 DMA rounds per patch
+    if (P < 2) P = 2;
+    const size_t lds = (size_t)6 * 8192 + (size_t)2 * P * 8192;
+    if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }
+  }
 }
 
 void conv_params(const flope_engine* e, const std::vector<Buf>& bufs, const Conv& c, int batch, ConvP* p) {
@@ -299,6 +313,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     int s = flope_conv_mfma_init();
     if (s == 0) s = flope_stem_init();
     if (s == 0) s = flope_stem_pool_init();
+    if (s == 0) s = flope_conv_stag_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
   const size_t B = (size_t)max_batch;
@@ -366,7 +381,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
   CREATE_TRY(hipMalloc((void**)&e->feat, B * 512 * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->hidden, B * (size_t)e->bod * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->r9_scratch, B * 9 * sizeof(float)));
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) {
     CREATE_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
   }
@@ -385,11 +400,11 @@ extern "C" int flope_destroy(flope_handle e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
-  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); }
+  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); }
   void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
-  for (int i = 0; i < 2; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
+  for (int i = 0; i < 4; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   delete e;
   return FLOPE_OK;
@@ -400,7 +415,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   int prev;
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
-  else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value >= 2 ? 2 : 1; return prev; }
+  else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value != 0; }
+  else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
   else if (!strcmp(name, "fuse_stem")) { prev = e->opt_fuse_stem; e->opt_fuse_stem = value != 0; return prev; }
   else if (!strcmp(name, "ldspad")) { prev = e->opt_ldspad; e->opt_ldspad = value; return prev; }
   else if (!strcmp(name, "dbg")) { prev = e->opt_dbg; e->opt_dbg = value; return prev; }
@@ -436,7 +452,10 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
     if ((rc = fold(e, ts, c.name, c.bn, c.cout, c.cin, c.k, &wf, &bf)) != 0) return rc;
     if ((rc = upload(e, bf, (void**)&c.bias)) != 0) return rc;
     if (e->dtype == FLOPE_DT_F32) { if ((rc = upload(e, naive_layout(wf, c.cout, c.cin, c.k), (void**)&c.w_naive)) != 0) return rc; }
-    else { if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc; }
+    else {
+      if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc;
+      if (c.k == 3 && c.stride == 1 && c.cout >= 128 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
+    }
   }
   // head (fp32 as stored)
   const float* w1 = ts.get(e, "base.fc.0.weight", {e->bod, 512}, &rc); if (!w1) return rc;
@@ -511,6 +530,11 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       p.in_off = c.k == 3 ? 0 : 1; p.relu = c.relu;
       SMARK();
       K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
+    } else if (c.stag) {
+      ConvP p; conv_params(e, vb, c, batch, &p);
+      p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + 255) / 256; p.ntiles = c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
+      SMARK();
+      K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, c.stag_lds, stream));
     } else {
       ConvP p; conv_params(e, vb, c, batch, &p);
       SMARK();
@@ -538,19 +562,21 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   e->ev_n = 0;
   e->last_fused = e->opt_fuse_stem && e->dtype != FLOPE_DT_F32;
   e->last_batch = batch;
-  const int ns = (e->opt_streams >= 2 && !e->opt_profile && batch >= 64) ? 2 : 1;
+  int ns = (e->opt_streams >= 2 && !e->opt_profile) ? e->opt_streams : 1;
+  while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
   if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true);
   hipStream_t user = (hipStream_t)stream;
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
-  const int half = (batch + 1) / 2;
-  for (int s = 0; s < 2; ++s) {
+  // slices are launched layer-interleaved?  No: each slice's whole sequence goes to its own stream; the
+  // hardware queues interleave them, and a slice's short tail round overlaps another slice's next launch.
+  for (int s = 0; s < ns; ++s) {
     HIP_TRY(e, hipStreamWaitEvent(e->side[s], e->ev_fork, 0));
-    const int start = s == 0 ? 0 : half, cnt = s == 0 ? half : batch - half;
+    const int start = (int)((long)batch * s / ns), cnt = (int)((long)batch * (s + 1) / ns) - start;
     int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(e->ev_join[s], e->side[s]));
   }
-  for (int s = 0; s < 2; ++s) HIP_TRY(e, hipStreamWaitEvent(user, e->ev_join[s], 0));
+  for (int s = 0; s < ns; ++s) HIP_TRY(e, hipStreamWaitEvent(user, e->ev_join[s], 0));
   return FLOPE_OK;
 }
 
@@ -639,6 +665,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     int BM, BN; tile_dims(c.cfg, &BM, &BN);
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
+    else if (c.stag) snprintf(k, sizeof k, "conv_stag_kernel<256x128>");
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
@@ -658,6 +685,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
   snprintf(line, sizeof line, "stem: tiles/img=%d rows=%d lds=%zu\n", e->stem_tiles, e->stem_rows, e->stem_lds);
   s += line;
   for (const Conv& c : e->convs) {
+    if (c.stag) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);
     s += line;

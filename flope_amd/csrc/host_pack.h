@@ -75,6 +75,29 @@ inline std::vector<uint16_t> pack_conv(const std::vector<float>& wf, int cout, i
   return out;
 }
 
+// conv_stag image: folded 3x3 weights wf[cout][cin][3][3] -> [ntile (cout/128)][hc*9 + tap][128 rows][32 k],
+// 64-byte rows, 16-byte slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1}; rows permuted as in pack_conv
+inline std::vector<uint16_t> pack_conv32(const std::vector<float>& wf, int cout, int cin, int dtype) {
+  static const int h[4] = {0, 2, 3, 1};
+  const int ntiles = cout / 128, nhc = cin / 32;
+  std::vector<uint16_t> out((size_t)cout * cin * 9);
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int hc = 0; hc < nhc; ++hc)
+      for (int tap = 0; tap < 9; ++tap) {
+        const size_t tile = ((size_t)nt * nhc * 9 + (size_t)hc * 9 + tap) * 128 * 32;
+        const int ky = tap / 3, kx = tap % 3;
+        for (int rl = 0; rl < 128; ++rl) {
+          const int co = nt * 128 + lds_row_to_channel(rl);
+          for (int kk = 0; kk < 32; ++kk) {
+            const float v = wf[(((size_t)co * cin + hc * 32 + kk) * 3 + ky) * 3 + kx];
+            const int slot = (kk >> 3) ^ h[(rl >> 2) & 3];
+            out[tile + (size_t)rl * 32 + slot * 8 + (kk & 7)] = cvt16(v, dtype);
+          }
+        }
+      }
+  return out;
+}
+
 // stem weights wf[64][3][7][7] -> [7 ky][64 rows][32 k = kx*4 + c] images (64-byte rows,
 // slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1})
 inline std::vector<uint16_t> pack_stem(const std::vector<float>& wf, int dtype) {
