@@ -255,3 +255,28 @@ def test_error_paths(state_dict):
     with pytest.raises(RuntimeError, match="non-finite"):
         e.load_state_dict(bad)
     e.close()
+
+
+def test_detection_rows_harness_vs_oracle(state_dict, tmp_path):
+    """scripts/test_posenet.py:104-161 counterpart: 15-column rows, '%.7f' text file."""
+    from flope_amd.harness import detection_rows, write_detection_file
+    from sunflower.models.posenet import PoseResNet
+    rgb, mask, _, boxes = _scene(23)
+    model = PoseResNet().to("cuda")
+    model.load_state_dict(state_dict)
+    rows = detection_rows(model, rgb, mask, boxes, crop_size=256)
+    keep = [bb for bb in boxes if P.bb_in_frame(P.squarify_bb(bb), rgb.shape)]
+    sq = [P.squarify_bb(bb) for bb in keep]
+    crops = torch.as_tensor(P.crop_batch(rgb, mask, sq, 256), dtype=torch.float32).permute(0, 3, 1, 2)
+    Rref = O.procrustes_to_rotmat(O.forward(state_dict, crops)).numpy()
+    ref = P.detection_rows(np.array(keep), Rref)
+    assert rows.shape == ref.shape == (len(keep), 15)
+    np.testing.assert_array_equal(rows[:, :6], ref[:, :6])
+    assert np.abs(rows[:, 6:] - ref[:, 6:]).max() <= 1e-3
+    f = tmp_path / "frame_00000.txt"
+    write_detection_file(f, rows)
+    back = np.loadtxt(f).reshape(-1, 15)
+    np.testing.assert_allclose(back, rows, atol=5e-8)
+    assert all(len(tok.split(".")[1]) == 7 for tok in f.read_text().split())
+    write_detection_file(f, detection_rows(model, rgb, mask, boxes[-2:-1], crop_size=256))   # nothing survives
+    assert f.read_text() == ""

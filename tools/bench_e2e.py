@@ -1,0 +1,54 @@
+"""BASELINE cfg3: end-to-end frames/s of the live_pose-style path on synthetic 1080p frames with a synthetic
+detector (boxes + mask given): frame/mask/depth H2D -> depth lift -> crop+Lanczos -> PoseResNet -> Procrustes
+-> yaw-null -> Rt -> D2H.   python tools/bench_e2e.py [n_flowers ...]"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "flope_amd")]
+from flope_amd.weights import synthetic_state_dict  # noqa: E402
+from sunflower.predictor.fast_pose_predictor import FastPosePredictor  # noqa: E402
+
+
+def scene(n, H=1080, W=1920, seed=0):
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    depth = (400 + rng.normal(0, 4, (H, W))).astype(np.uint16)
+    yy, xx = np.mgrid[:H, :W]
+    boxes = []
+    for i in range(n):
+        r = int(rng.integers(40, 90)); cx = int(rng.integers(r + 12, W - r - 12)); cy = int(rng.integers(r + 12, H - r - 12))
+        mask[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 255
+        boxes.append([cx - r - 3, cy - r, cx + r + 4, cy + r + 2])
+    return rgb, mask, depth, np.array(boxes, dtype=np.int16)
+
+
+def main():
+    counts = [int(a) for a in sys.argv[1:]] or [4, 16, 31]
+    tmp = tempfile.mkdtemp()
+    ckpt, intr = os.path.join(tmp, "posenet.pth"), os.path.join(tmp, "intrinsics.yaml")
+    torch.save(synthetic_state_dict(0), ckpt)
+    open(intr, "w").write(yaml.safe_dump(dict(fx=1400.0, fy=1400.0, cx=960.0, cy=540.0, h=1080, w=1920)))
+    for n in counts:
+        rgb, mask, depth, boxes = scene(n)
+        pred = FastPosePredictor("cuda", lambda img: (boxes, mask), ckpt, intr)
+        for _ in range(3):
+            Rt = pred.get_flower_poses(rgb, depth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); it = 20
+        for _ in range(it):
+            Rt = pred.get_flower_poses(rgb, depth)
+        dt = (time.perf_counter() - t0) / it
+        print(f"[e2e] 1080p, {n} boxes -> {0 if Rt is None else Rt.shape[0]} poses (512x512 crops): {dt*1e3:.2f} ms/frame, "
+              f"{1/dt:.1f} frames/s, {(0 if Rt is None else Rt.shape[0])/dt:.0f} poses/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
