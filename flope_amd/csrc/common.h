@@ -55,6 +55,12 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+// n / d for 0 <= n < 2^31 as one 64-bit multiply and a shift: M = ceil(2^(31+l) / d), l = ceil(log2 d),
+// q = (n * M) >> (31 + l)   (exact: the error term n*e / (d*2^(31+l)) is < 2^-l <= 1/d)
+__device__ __forceinline__ int fastdiv(int n, unsigned mg, unsigned sh) {
+  return (int)(((unsigned long long)(unsigned)n * mg) >> sh);
+}
+
 // ---------------------------------------------------------------------------
 // Implicit-GEMM convolution on MFMA (conv_mfma.hip)
 struct ConvP {
@@ -75,6 +81,8 @@ struct ConvP {
   int tiles_per_image;
   int patch_rows_max;  // patch mode: LDS rows reserved
   int dbg;             // timing experiments only: bit0 skip weight staging, bit1 skip pixel staging, bit2 skip MFMA
+  unsigned mg_hw, sh_hw, mg_w, sh_w;   // n / (Ho*Wo) and n / Wo as multiply-shift (host: fastdiv_magic), n < 2^31
+  int total_tiles;     // conv_stag: persistent grid walks tiles blockIdx.x + k*gridDim.x < total_tiles
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

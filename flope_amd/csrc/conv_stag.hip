@@ -28,76 +28,102 @@ __device__ __forceinline__ int tile_px_s(int c) { return c < 4 ? 2 * c : (c < 12
 
 // PT = LDS-DMA rounds (of 512 x 16 B) per patch burst: a compile-time constant so that every s_waitcnt in
 // the main loop is an immediate and the 18-step body (two half-chunks x nine taps) has no runtime control
-// flow beyond the group test -- r01's first version of this kernel spent ~0.5 us per phase in scalar
-// bookkeeping (ring slot, tap decode, wait-count switch), more than the 16 MFMAs it was wrapped around.
-template <typename T, int PT>
+// flow -- r01's first version of this kernel spent ~0.5 us per phase in scalar bookkeeping (ring slot, tap
+// decode, wait-count switch), more than the 16 MFMAs it was wrapped around.
+// BN = 128: 256-pixel tiles, each 4-wave group is 2 (px) x 2 (ch) waves.  BN = 64 (layer 1): 512-pixel tiles,
+// each group is 4 (px) x 1 (ch) waves and the 4 KB weight tile is moved by waves 0..3 only.
+// RES: the layer has a residual input (fixes the number of VM ops of the epilogue at compile time).
+//
+// PERSISTENT: the grid is at most one workgroup per CU and workgroup b walks tiles b, b+G, b+2G, ...
+// (G % ntiles == 0, so its channel tile -- weight panel, bias -- never changes).  The step stream simply
+// continues across a tile boundary: the weight ring wraps to the panel's first tiles and the last half-chunk's
+// patch burst fetches the NEXT tile's first patch, so no DMA latency is ever re-exposed; only the register
+// epilogue + the next tile's address table sit between two tiles (one group at a time, the other keeps going).
+template <typename T, int PT, int BN, bool RES>
 __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
-  constexpr int BM = 256, BN = 128, NB = 6, TILE_B = BN * 64;     // 8 KB weight tile per step
+  constexpr int BM = BN == 128 ? 256 : 512, GP = BM / 2, TILE_B = BN * 64;   // 8 / 4 KB weight tile per (half-chunk, tap)
+  constexpr int NBD = 3, DT_B = 2 * TILE_B;                 // ring of 3 double tiles (one double step = two taps)
+  constexpr int TG = DT_B / 8192;                           // LDS-DMA ops per wave per double tile (2 / 1)
   constexpr int MT = 4, NT = 4;
   constexpr int PATCH_B = PT * 8192;                              // bytes of one patch buffer
+  constexpr int EPI_OPS = MT * 2 + (RES ? MT * 2 : 0);            // 16-byte stores (+ residual loads) per lane per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;                                   // 2 patch buffers (first: their offsets stay ds_read immediates)
-  char* const Bs = smem + 2 * PATCH_B;                     // NB x 8 KB weight ring
+  char* const Bs = smem + 2 * PATCH_B;                     // NBD double-tile weight ring
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int group = wave >> 2, wl = wave & 3, wpx = wl & 1, wch = wl >> 1;
+  const int group = wave >> 2, wl = wave & 3;
+  const int wpx = BN == 128 ? (wl & 1) : wl, wch = BN == 128 ? (wl >> 1) : 0;
   const int g = lane >> 4, r16 = lane & 15;
   const int pcol = tile_px_s(r16);
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
+  const int G = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, G);
+  const int ntile = lb % p.ntiles;                         // constant over this workgroup's tiles
   const int HoWo = p.Ho * p.Wo;
   const int nhc = p.Cin / 32;                              // even: Cin is a multiple of 64
-  const int NS = nhc * 9;
-  const int m0 = mtile * BM, mend = min(m0 + BM, p.M);
-
-  // ---- patch geometry (same as conv_mfma patch mode, 64-byte pixels)
-  const int b0 = m0 / HoWo, ho0 = (m0 - b0 * HoWo) / p.Wo;
-  const int ml = mend - 1, b1 = ml / HoWo, ho1 = (ml - b1 * HoWo) / p.Wo;
-  const int R0 = b0 * p.Hip + ho0, R1 = b1 * p.Hip + ho1 + 2;
-  const char* const patch_src = (const char*)p.in + (size_t)R0 * p.Wip * p.Cin * 2;
-  const int patch_pieces = (R1 - R0 + 1) * p.Wip * 4;      // 16-byte pieces of one half-chunk patch (<= PT*512)
+  const int NS = nhc * 9;                                  // (half-chunk, tap) steps per tile; NS/2 double steps
   const size_t pixB = (size_t)p.Cin * 2;
-  int pi0[MT];
-#pragma unroll
-  for (int pt = 0; pt < MT; ++pt) {
-    const int m = min(m0 + group * 128 + wpx * 64 + pt * 16 + pcol, mend - 1);
-    const int b = m / HoWo, r = m - b * HoWo, ho = r / p.Wo, wo = r - ho * p.Wo;
-    pi0[pt] = (b * p.Hip + ho - R0) * p.Wip + wo;
-  }
-  // Everything a step needs is precomputed so the loop body is LDS reads, MFMAs, one DMA issue and
-  // waits only (the r01 counters showed ~2.8 address VALU ops per MFMA otherwise -- the load half of a
-  // phase then outlasts the 16-MFMA half it is supposed to hide under):
-  //   psrc[rr]   per-lane 32-bit source offsets of the PT patch rounds (constant over half-chunks)
+  const size_t rowB = (size_t)p.Wip * pixB;
+
+  // Everything a step needs is precomputed so the loop body is LDS reads, MFMAs, one DMA issue and waits:
+  //   psrc[rr]    per-lane 32-bit source offsets of the PT patch rounds (tile independent: the burst always
+  //               moves PT*512 pieces; what lies past the tile's rows is never read back -- the activation
+  //               buffers carry 1 MB of slack so the over-read stays inside the allocation)
   //   xoff[t][pt] LDS byte offset of this lane's pixel fragment for tap t (buffer / ring slot are immediates)
-  unsigned psrc[PT];
-#pragma unroll
-  for (int rr = 0; rr < PT; ++rr) {
-    const int q = min(rr * 512 + wave * 64 + lane, patch_pieces - 1);
+  // round rr moves pieces rr*512 + wave*64 + lane: pixel rr*128 + wave*16 + (lane>>2), whose swizzle term
+  // ((pixel >> 2) & 3) does not depend on rr or wave -> one per-lane offset + a uniform rr stride
+  unsigned psrc0;
+  {
+    const int q = wave * 64 + lane;
     const int pi = q >> 2, js = (q & 3) ^ ((pi >> 2) & 3);
-    psrc[rr] = (unsigned)(pi * (int)pixB + js * 16);
+    psrc0 = (unsigned)(pi * (int)pixB + js * 16);
   }
-  int xoff[9][MT];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int pt = 0; pt < MT; ++pt) {
-      const int pi = pi0[pt] + (t / 3) * p.Wip + (t % 3);
-      xoff[t][pt] = (pi << 6) + ((g ^ ((pi >> 2) & 3)) << 4);
-    }
-  // weight tiles: [ntile][step][128 rows][32 k]; wave w moves 1 KiB piece w of every tile:
-  // uniform base (SGPR pair) + per-lane 32-bit offset -> no address VALU at issue time
-  const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + wave * 1024;
+  const size_t round_stride = 128 * pixB;
+  const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + wave * 1024;   // + g*8192 for op g of a double tile
   const unsigned lane16 = lane * 16;
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
   const int wbase = 2 * PATCH_B + (wch * 64 + r16) * 64 + ((g ^ wsw) << 4);
+  const int cb = ntile * BN + wch * 64 + g * 16;
+  float bias[NT * 4];
+#pragma unroll
+  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
 
-#define ISSUE_PATCH(hc_, buf_)                                                                                 \
+  // ---- tile geometry: wave-uniform part (first pixel, patch origin) and per-lane part (xoff, output offsets)
+  int m0, mend, R0;                                        // current tile
+  const char* patch_src;
+  int n_m0 = 0, n_mend = 0, n_R0 = 0;                      // next tile of this workgroup
+  const char* n_patch_src = nullptr;
+  bool has_next;
+#define TILE_GEOM(tile_, m0_, mend_, R0_, src_)                                                                \
   do {                                                                                                         \
-    const char* src_ = patch_src + (hc_) * 64;          /* wave-uniform */                                      \
+    m0_ = ((tile_) / p.ntiles) * BM;                                                                           \
+    mend_ = min(m0_ + BM, p.M);                                                                                \
+    const int b0_ = fastdiv(m0_, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0_ - b0_ * HoWo, p.mg_w, p.sh_w);          \
+    R0_ = b0_ * p.Hip + ho0_;                                                                                  \
+    src_ = (const char*)p.in + (size_t)R0_ * rowB;                                                             \
+  } while (0)
+  int xoff[9][MT];
+#define LANE_SETUP()                                                                                           \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
+      const int mm_ = m0 + group * GP + wpx * 64 + pt * 16 + pcol;                                             \
+      const int m_ = min(mm_, mend - 1);                                                                       \
+      const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - b_ * HoWo;                                       \
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;                                      \
+      const int pi0_ = (b_ * p.Hip + ho_ - R0) * p.Wip + wo_;                                                  \
+      _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                          \
+        const int pi = pi0_ + (t / 3) * p.Wip + (t % 3);                                                       \
+        xoff[t][pt] = (pi << 6) + ((g ^ ((pi >> 2) & 3)) << 4);                                                \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+
+#define ISSUE_PATCH(src_, buf_)                                                                                \
+  do {                                                                                                         \
     _Pragma("unroll") for (int rr = 0; rr < PT; ++rr)                                                          \
-      GLDS16(src_ + psrc[rr], Ps + (buf_) * PATCH_B + (rr * 512 + wave * 64) * 16);                            \
+      GLDS16((src_) + rr * round_stride + psrc0, Ps + (buf_) * PATCH_B + (rr * 512 + wave * 64) * 16);         \
   } while (0)
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define BARRIER()                                                                                              \
@@ -109,101 +135,196 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 
-  frag wf[NT], xf[MT];
+  frag wf[2][NT], xf[2][MT];
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads of one step: ring slot / patch buffer are literals, the tap shift a scalar
-#define LOADF(slot_, buf_, tap_)                                                                               \
+  // fragment reads of one double step: ring slot, patch buffers and taps are literals
+#define LOADF(slot_, buf0_, tap0_, buf1_, tap1_)                                                               \
   do {                                                                                                         \
-    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
-      wf[ct] = *(const frag*)(smem + wbase + (slot_) * TILE_B + ct * 1024);                                    \
-    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                          \
-      xf[pt] = *(const frag*)(smem + xoff[tap_][pt] + (buf_) * PATCH_B);                                       \
+    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) {                                                        \
+      wf[0][ct] = *(const frag*)(smem + wbase + (slot_) * DT_B + ct * 1024);                                   \
+      wf[1][ct] = *(const frag*)(smem + wbase + (slot_) * DT_B + TILE_B + ct * 1024);                          \
+    }                                                                                                          \
+    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
+      xf[0][pt] = *(const frag*)(smem + xoff[tap0_][pt] + (buf0_) * PATCH_B);                                  \
+      xf[1][pt] = *(const frag*)(smem + xoff[tap1_][pt] + (buf1_) * PATCH_B);                                  \
+    }                                                                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
   } while (0)
 #define MFMAS()                                                                                                \
   do {                                                                                                         \
-    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                          \
-      _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], acc[pt][ct]); \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                              \
+      _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                        \
+        _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                      \
+          acc[pt][ct] = Elem<T>::mfma(wf[h][ct], xf[h][pt], acc[pt][ct]);                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
+#define ISSUE_DT(dt_, slot_)                                                                                   \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int o = 0; o < TG; ++o)                                                             \
+      GLDS16(b_base + (size_t)(dt_) * DT_B + o * 8192 + lane16, Bs + (slot_) * DT_B + o * 8192 + wave * 1024); \
+  } while (0)
 
-  // ---- prologue: patch of half-chunk 0, tiles 0..NB-1 (NS >= 18 > NB always)
-  ISSUE_PATCH(0, 0);
-#pragma unroll
-  for (int t = 0; t < NB - 1; ++t) GLDS16(b_base + (size_t)t * TILE_B + lane16, Bs + t * TILE_B + wave * 1024);
-  WAIT_VM(NB - 2);                             // patch 0 and tile 0 landed (tiles 1..NB-2 may fly)
+  // ---- first tile of this workgroup + the one after it
+  int tile = lb;
+  TILE_GEOM(tile, m0, mend, R0, patch_src);
+  has_next = tile + G < p.total_tiles;
+  if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
+  LANE_SETUP();
+
+  // ---- prologue: patch of half-chunk 0, double tiles 0 and 1
+  ISSUE_PATCH(patch_src, 0);
+  ISSUE_DT(0, 0);
+  ISSUE_DT(1, 1);
+  WAIT_VM(TG);                                 // patch 0 and double tile 0 landed (double tile 1 may fly)
   BARRIER();
   if (group == 1) BARRIER();                   // group B runs one phase behind group A
 
-  // Every wave executes the SAME stream per step j = 18*hcp + U (no group tests inside the loop):
-  //     issue tile j+NB-1 into the ring slot step j-1 just released (tile t lives in slot t % NB; clamped to
-  //         the last tile: a harmless re-load keeps the op count per step constant); at tap 0 also the next
-  //         half-chunk's patch (clamped likewise)
-  //     LOADF(j)  ->  wait for this wave's piece of tile j+1  ->  barrier  ->  16 MFMAs  ->  barrier
+  // Every wave executes the SAME stream per double step D (two (half-chunk, tap) pairs u = 2D, 2D+1 of the
+  // 18 that make up two half-chunks), no group tests inside the loop:
+  //     issue double tile D+2 into the ring slot double step D-1 just released (double tile t lives in slot
+  //         t % 3; past the end of the panel it wraps to the panel's start = the next tile's first steps);
+  //         at D = 0 the patch of this body's second half-chunk, at D = 5 the patch of the NEXT body's first
+  //         half-chunk (or the next tile's) -- each into the buffer whose last reader was one double step ago
+  //     LOADF(D): 16 ds_read_b128  ->  wait for this wave's pieces of double tile D+1  ->  barrier
+  //     32 MFMAs  ->  barrier
   // and group B is one barrier behind group A, so in every physical phase one group is in its MFMA half
-  // while the other is in its load half.  Hazards (phi = physical phase; A: L(j) at 2j-1, M(j) at 2j;
-  // B: L(j) at 2j, M(j) at 2j+1): slot of step j-1 is last read by B's L(j-1) at phi 2j-2, refilled at
-  // phi >= 2j-1; tile j is waited for by A after L(j-1) (phi 2j-3) and by B after L(j-1) (phi 2j-2), both
-  // before the barrier that precedes A's L(j) at phi 2j-1.
-  // Younger VM ops than tile j+1 at the wait: NB-2 tiles, plus the PT patch rounds when this half-chunk's
-  // burst (issued at its tap 0) is younger than tile j+1, i.e. for taps 0..NB-2.
-  int jn = NB - 1;                                          // tile to issue at the start of the next step
-  int hc = 0;
-#define STEP(U)                                                                                           \
+  // while the other is in its load half (A: L(D) at phase 2D-1, M(D) at 2D; B: L(D) at 2D, M(D) at 2D+1).
+  // Hazards: slot of D-1 is last read by B's L(D-1) at phase 2D-2, refilled at phase >= 2D-1; double tile D is
+  // waited for by every wave right after its own L(D-1), i.e. before the barrier that precedes A's L(D).
+  // Patch buffer 0 is last read at D = 4 (tap 8 of the first half-chunk), buffer 1 at D = 8.
+  // Younger VM ops than double tile D+1 at the wait: the TG ops of double tile D+2, plus the PT patch rounds
+  // when a burst was issued at double step D-1 or D (D in {0,1,5,6}), plus -- at D = 0 right after a tile
+  // boundary -- the EPI_OPS stores / residual loads of the epilogue that ran in between.
+  int dn = 2;                                               // double tile to issue at the start of the next double step
+  int hc = 0;                                               // first half-chunk of the current body
+  bool after_epi = false;
+  const int ND = NS / 2;                                    // double steps per tile
+#define DSTEP(D)                                                                                               \
   do {                                                                                                         \
-    constexpr int TAP_ = (U) % 9, BUF_ = (U) / 9, SLOT_ = (U) % NB, PSLOT_ = ((U) + NB - 1) % NB;              \
-    constexpr int WN_ = NB - 2 + (TAP_ <= NB - 2 ? PT : 0);                                                    \
+    constexpr int U0_ = 2 * (D), U1_ = 2 * (D) + 1;                                                            \
+    constexpr int WN_ = TG + (((D) == 0 || (D) == 1 || (D) == 5 || (D) == 6) ? PT : 0);                        \
     {                                                                                                          \
-      const int ti_ = jn < NS - 1 ? jn : NS - 1;                                                               \
-      GLDS16(b_base + (size_t)ti_ * TILE_B + lane16, Bs + PSLOT_ * TILE_B + wave * 1024);                      \
-      ++jn;                                                                                                    \
+      const int di_ = dn < ND ? dn : dn - ND;                                                                  \
+      ISSUE_DT(di_, ((D) + 2) % NBD);                                                                          \
+      ++dn;                                                                                                    \
     }                                                                                                          \
-    if (TAP_ == 0) {                                                                                           \
-      const int nh_ = hc + 1 < nhc ? hc + 1 : hc;                                                              \
-      ISSUE_PATCH(nh_, BUF_ ^ 1);                                                                              \
+    if ((D) == 0) ISSUE_PATCH(patch_src + (hc + 1) * 64, 1);                                                   \
+    if ((D) == 5) {                                                                                            \
+      const char* s_ = hc + 2 < nhc ? patch_src + (hc + 2) * 64 : (has_next ? n_patch_src : patch_src);        \
+      ISSUE_PATCH(s_, 0);                                                                                      \
     }                                                                                                          \
-    if (TAP_ == 8) ++hc;                                                                                       \
-    LOADF(SLOT_, BUF_, TAP_);                                                                                  \
-    WAIT_VM(WN_);                                                                                              \
+    LOADF((D) % NBD, U0_ / 9, U0_ % 9, U1_ / 9, U1_ % 9);                                                      \
+    if ((D) == 0 && after_epi) WAIT_VM(WN_ + EPI_OPS);                                                         \
+    else WAIT_VM(WN_);                                                                                         \
     BARRIER();                                                                                                 \
     MFMAS();                                                                                                   \
     BARRIER();                                                                                                 \
   } while (0)
-  for (int hcp = 0; hcp < nhc / 2; ++hcp) {
-    STEP(0);  STEP(1);  STEP(2);  STEP(3);  STEP(4);  STEP(5);  STEP(6);  STEP(7);  STEP(8);
-    STEP(9);  STEP(10); STEP(11); STEP(12); STEP(13); STEP(14); STEP(15); STEP(16); STEP(17);
+
+  for (;;) {
+    for (int hcp = 0; hcp < nhc / 2; ++hcp) {
+      DSTEP(0); DSTEP(1); DSTEP(2); DSTEP(3); DSTEP(4); DSTEP(5); DSTEP(6); DSTEP(7); DSTEP(8);
+      after_epi = false;
+      hc += 2;
+    }
+    // ---- tile finished for this wave: + bias (+ residual) (ReLU) -> 16-bit padded NHWC, straight from registers
+    const bool full_tile = mend - m0 == BM;
+    {
+      size_t ooff[MT];
+      bool ok[MT];
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) {
+        const int mm = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
+        ok[pt] = mm < mend;
+        const int mc = min(mm, mend - 1);                    // clamped: loads below are always legal
+        const int b_ = fastdiv(mc, p.mg_hw, p.sh_hw), r_ = mc - b_ * HoWo;
+        const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+        ooff[pt] = ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + cb) * 2;
+      }
+      // all residual loads first (one latency, not one per pixel tile), then compute + store
+      u32x4 rv[RES ? MT : 1][2];
+      if constexpr (RES) {
+#pragma unroll
+        for (int pt = 0; pt < MT; ++pt) {
+          const char* rp = (const char*)p.res + ooff[pt];
+          rv[pt][0] = *(const u32x4*)rp;
+          rv[pt][1] = *(const u32x4*)(rp + 16);
+        }
+      }
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) {
+        float v[NT * 4];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q] + bias[ct * 4 + q];
+        if constexpr (RES) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[c * 8 + q * 2] += unpack_lo<T>(rv[pt][c][q]);
+              v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[pt][c][q]);
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int i = 0; i < NT * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (ok[pt]) {
+          char* op = (char*)p.out + ooff[pt];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
+            *(u32x4*)(op + c * 16) = o;
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (!has_next) break;
+    // ---- next tile: geometry, address table; the step stream (ring, patch buffers) just continues
+    tile += G;
+    m0 = n_m0; mend = n_mend; R0 = n_R0; patch_src = n_patch_src;
+    has_next = tile + G < p.total_tiles;
+    if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
+    LANE_SETUP();
+    dn -= ND;
+    hc = 0;
+    if (full_tile) {
+      after_epi = true;                        // the epilogue issued exactly EPI_OPS VM ops per lane
+    } else {
+      WAIT_VM(0);                              // partial tile: op count unknown -> drain once, static counts stay valid
+    }
   }
   if (group == 0) BARRIER();                                // every wave executes the same number of barriers
-  WAIT_VM(0);                                               // drain the clamped tail re-loads before LDS is released
-#undef STEP
+  WAIT_VM(0);                                               // drain the wrapped-around tail DMAs before LDS is released
+#undef DSTEP
+#undef ISSUE_DT
 #undef ISSUE_PATCH
 #undef WAIT_VM
 #undef BARRIER
 #undef LOADF
 #undef MFMAS
-
-  // ---- epilogue: + bias (+ residual) (ReLU) -> 16-bit padded NHWC
-  const int cb = ntile * BN + wch * 64 + g * 16;
-  float bias[NT * 4];
-#pragma unroll
-  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
-#pragma unroll
-  for (int pt = 0; pt < MT; ++pt) {
-    const int m = m0 + group * 128 + wpx * 64 + pt * 16 + pcol;
-    conv_epilogue_px<T, NT>(p, acc[pt], m, m < mend, cb, bias, HoWo);
-  }
+#undef TILE_GEOM
+#undef LANE_SETUP
 }
 
 template <typename T>
 static hipError_t stag_attr() {
   hipError_t e = hipSuccess;
-#define A(PT_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A(2) A(4) A(6) A(8)
+#define A(PT_, BN_) \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A(2, 128) A(4, 128) A(6, 128) A(8, 128) A(2, 64) A(4, 64) A(6, 64) A(8, 64)
 #undef A
   return e;
 }
@@ -214,20 +335,26 @@ extern "C" int flope_conv_stag_init() {
   return (int)e;
 }
 
-template <typename T>
-static void stag_launch(const ConvP& p, int pt, size_t lds, hipStream_t st) {
-  const dim3 grid(p.mtiles * p.ntiles), block(512);
+template <typename T, int BN, bool RES>
+static void stag_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
+  const dim3 grid(grid_blocks), block(512);
   switch (pt) {
-    case 2: hipLaunchKernelGGL((conv_stag_kernel<T, 2>), grid, block, lds, st, p); break;
-    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4>), grid, block, lds, st, p); break;
-    case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((conv_stag_kernel<T, 8>), grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL((conv_stag_kernel<T, 2, BN, RES>), grid, block, lds, st, p); break;
+    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, BN, RES>), grid, block, lds, st, p); break;
+    case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, BN, RES>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, BN, RES>), grid, block, lds, st, p); break;
   }
 }
 
-// p->patch_rows_max carries PT (2, 4, 6 or 8 DMA rounds per patch buffer); lds = 6*8 KiB + 2*PT*8 KiB
-extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, size_t lds, void* stream) {
-  if (dtype == 0) stag_launch<bf16_t>(*p, p->patch_rows_max, lds, (hipStream_t)stream);
-  else            stag_launch<f16_t>(*p, p->patch_rows_max, lds, (hipStream_t)stream);
+// p->patch_rows_max carries PT (2, 4, 6 or 8 DMA rounds per patch buffer); Cout == 64 selects the 512 x 64 tile;
+// p->total_tiles = mtiles * ntiles; grid_blocks <= total_tiles and a multiple of ntiles;
+// lds = 2*PT*8 KiB + 3 * 2 * (BN*64 B)
+extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int pt = p->patch_rows_max;
+#define GO(T, BN_) (p->res ? stag_launch<T, BN_, true>(*p, pt, grid_blocks, lds, st) : stag_launch<T, BN_, false>(*p, pt, grid_blocks, lds, st))
+  if (p->Cout == 64) { if (dtype == 0) GO(bf16_t, 64); else GO(f16_t, 64); }
+  else               { if (dtype == 0) GO(bf16_t, 128); else GO(f16_t, 128); }
+#undef GO
   return (int)hipGetLastError();
 }

@@ -30,7 +30,7 @@ extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int 
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
 extern "C" int flope_conv_stag_init();
-extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, size_t lds, void* stream);
+extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_stem_pool_init();
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
                                       const void* w, const float* bias, void* out, int dtype, void* stream);
@@ -44,6 +44,7 @@ thread_local std::string g_last_error;
 constexpr double kBnEps = 1e-5;
 constexpr size_t kLdsTwoBlocks = 80 * 1024;   // <= this: two workgroups per CU
 constexpr size_t kLdsMax = 160 * 1024;
+constexpr size_t kBufSlack = 1 << 20;         // conv_stag's fixed-size patch DMA may read this far past the last pixel (zeros)
 
 struct Conv {
   std::string name, bn;
@@ -81,7 +82,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_stag = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 1, num_cus = 256, opt_stag = 2;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
@@ -193,13 +194,14 @@ void plan_conv(flope_engine* e, Conv& c) {
   c.ntiles = c.cout / BN;
   // second-generation kernel (conv_stag.hip): 256 x 128 tiles, 32-channel steps, double-buffered patch
   c.stag = 0;
-  if (e->opt_stag && c.k == 3 && c.stride == 1 && c.cout >= 128 && c.cin % 32 == 0 && c.cin >= 64) {
-    const int rows = patch_rows(c, B, 256, false);
+  if (e->opt_stag && c.k == 3 && c.stride == 1 && c.cin % 64 == 0 && (c.cout >= 128 || (c.cout == 64 && e->opt_stag >= 2))) {
+    const int sbm = c.cout == 64 ? 512 : 256, sbn = c.cout == 64 ? 64 : 128;
+    const int rows = patch_rows(c, B, sbm, false);
     const long pieces = (long)rows * Wip * 4;
     int P = (int)((pieces + 511) / 512);
     P = (P + 1) & ~1;                                  // kernel instantiations: 2, 4, 6, 8 DMA rounds per patch
     if (P < 2) P = 2;
-    const size_t lds = (size_t)6 * 8192 + (size_t)2 * P * 8192;
+    const size_t lds = (size_t)6 * sbn * 64 + (size_t)2 * P * 8192;   // 3 double tiles + 2 patch buffers
     if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }
   }
 }
@@ -217,6 +219,8 @@ void conv_params(const flope_engine* e, const std::vector<Buf>& bufs, const Conv
   p->per_image = c.per_image; p->tiles_per_image = c.tiles_per_image;
   p->mtiles = c.per_image ? batch * c.tiles_per_image : (p->M + BM - 1) / BM;
   p->ntiles = c.ntiles; p->patch_rows_max = c.rows_max; p->dbg = e->opt_dbg;
+  fastdiv_magic((unsigned)(c.hout * c.wout), &p->mg_hw, &p->sh_hw);
+  fastdiv_magic((unsigned)c.wout, &p->mg_w, &p->sh_w);
 }
 
 template <typename V>
@@ -309,6 +313,11 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     }                                                                                            \
   } while (0)
   CREATE_TRY(hipSetDevice(device_id));
+  {
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   if (dtype != FLOPE_DT_F32) {
     int s = flope_conv_mfma_init();
     if (s == 0) s = flope_stem_init();
@@ -338,7 +347,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     }
   }
   auto add_buf = [&](int C, int h, int w) {
-    Buf b; b.C = C; b.h = h; b.w = w; b.bytes = B * (h + 2) * (w + 2) * C * e->esz;
+    Buf b; b.C = C; b.h = h; b.w = w; b.bytes = B * (h + 2) * (w + 2) * C * e->esz + kBufSlack;
     e->bufs.push_back(b);
     return (int)e->bufs.size() - 1;
   };
@@ -415,7 +424,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   int prev;
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
-  else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value != 0; }
+  else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
+  else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
   else if (!strcmp(name, "fuse_stem")) { prev = e->opt_fuse_stem; e->opt_fuse_stem = value != 0; return prev; }
   else if (!strcmp(name, "ldspad")) { prev = e->opt_ldspad; e->opt_ldspad = value; return prev; }
@@ -454,7 +464,7 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
     if (e->dtype == FLOPE_DT_F32) { if ((rc = upload(e, naive_layout(wf, c.cout, c.cin, c.k), (void**)&c.w_naive)) != 0) return rc; }
     else {
       if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc;
-      if (c.k == 3 && c.stride == 1 && c.cout >= 128 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
+      if (c.k == 3 && c.stride == 1 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
     }
   }
   // head (fp32 as stored)
@@ -532,9 +542,15 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
     } else if (c.stag) {
       ConvP p; conv_params(e, vb, c, batch, &p);
-      p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + 255) / 256; p.ntiles = c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
+      const int sbm = c.cout == 64 ? 512 : 256;
+      p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + sbm - 1) / sbm; p.ntiles = c.cout == 64 ? 1 : c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
+      p.total_tiles = p.mtiles * p.ntiles;
+      // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile)
+      int gridb = e->opt_persist ? std::min(p.total_tiles, e->num_cus) : p.total_tiles;
+      gridb -= gridb % p.ntiles;
+      if (gridb < p.ntiles) gridb = p.ntiles;
       SMARK();
-      K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, c.stag_lds, stream));
+      K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, gridb, c.stag_lds, stream));
     } else {
       ConvP p; conv_params(e, vb, c, batch, &p);
       SMARK();
@@ -665,7 +681,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     int BM, BN; tile_dims(c.cfg, &BM, &BN);
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
-    else if (c.stag) snprintf(k, sizeof k, "conv_stag_kernel<256x128>");
+    else if (c.stag) snprintf(k, sizeof k, c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>");
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;

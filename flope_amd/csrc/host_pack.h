@@ -10,6 +10,15 @@
 
 namespace flope_host {
 
+// multiply-shift constants for n / d, 0 <= n < 2^31, 1 <= d < 2^31 (device: common.h fastdiv)
+inline void fastdiv_magic(unsigned d, unsigned* mg, unsigned* sh) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  const unsigned long long num = 1ull << (31 + l);
+  *mg = (unsigned)((num + d - 1) / d);
+  *sh = 31 + l;
+}
+
 // ---- host-side 16-bit conversions (round to nearest even) ---------------------
 inline uint16_t f32_to_bf16(float f) {
   uint32_t u; memcpy(&u, &f, 4);
@@ -75,19 +84,19 @@ inline std::vector<uint16_t> pack_conv(const std::vector<float>& wf, int cout, i
   return out;
 }
 
-// conv_stag image: folded 3x3 weights wf[cout][cin][3][3] -> [ntile (cout/128)][hc*9 + tap][128 rows][32 k],
+// conv_stag image: folded 3x3 weights wf[cout][cin][3][3] -> [ntile (cout/BN)][hc*9 + tap][BN rows][32 k], BN = min(cout,128),
 // 64-byte rows, 16-byte slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1}; rows permuted as in pack_conv
 inline std::vector<uint16_t> pack_conv32(const std::vector<float>& wf, int cout, int cin, int dtype) {
   static const int h[4] = {0, 2, 3, 1};
-  const int ntiles = cout / 128, nhc = cin / 32;
+  const int BN = cout == 64 ? 64 : 128, ntiles = cout / BN, nhc = cin / 32;
   std::vector<uint16_t> out((size_t)cout * cin * 9);
   for (int nt = 0; nt < ntiles; ++nt)
     for (int hc = 0; hc < nhc; ++hc)
       for (int tap = 0; tap < 9; ++tap) {
-        const size_t tile = ((size_t)nt * nhc * 9 + (size_t)hc * 9 + tap) * 128 * 32;
+        const size_t tile = ((size_t)nt * nhc * 9 + (size_t)hc * 9 + tap) * BN * 32;
         const int ky = tap / 3, kx = tap % 3;
-        for (int rl = 0; rl < 128; ++rl) {
-          const int co = nt * 128 + lds_row_to_channel(rl);
+        for (int rl = 0; rl < BN; ++rl) {
+          const int co = nt * BN + lds_row_to_channel(rl);
           for (int kk = 0; kk < 32; ++kk) {
             const float v = wf[(((size_t)co * cin + hc * 32 + kk) * 3 + ky) * 3 + kx];
             const int slot = (kk >> 3) ^ h[(rl >> 2) & 3];

@@ -77,14 +77,17 @@ def main():
     sd = synthetic_state_dict(0)
     e = PoseEngine(224, 224, 256, "f16"); print(e.describe_plan()); e.close()
     safe(parity, sd, 96, 80, 3, "f32", {})
+    safe(parity, sd, 224, 224, 48, "f16", dict(fuse_stem=1, stag=2, persist=1))
+    safe(parity, sd, 224, 224, 48, "f16", dict(fuse_stem=1, stag=1, persist=1))
+    safe(parity, sd, 224, 224, 48, "f16", dict(fuse_stem=1, stag=2, persist=0))
     for hw in ((224, 224, 5), (65, 71, 2), (130, 50, 3)):
-        safe(parity, sd, hw[0], hw[1], hw[2], "f16", dict(fuse_stem=1, stag=1))
+        safe(parity, sd, hw[0], hw[1], hw[2], "f16", dict(fuse_stem=1, stag=2))
     for dtype in ("f16", "bf16"):
-        for opts in [dict(patch=a, bm256=b, nbuf=c, fuse_stem=a, stag=b) for a in (0, 1) for b in (0, 1) for c in (2, 3)]:
+        for opts in [dict(patch=a, bm256=b, nbuf=c, fuse_stem=a, stag=2 * b) for a in (0, 1) for b in (0, 1) for c in (2, 3)]:
             safe(parity, sd, 96, 80, 3, dtype, opts)
             if not quick:
                 safe(parity, sd, 224, 224, 5, dtype, opts)
-    for opts in [dict(streams=1, stag=0), dict(streams=1, stag=1), dict(streams=2, stag=0), dict(streams=2, stag=1)]:
+    for opts in [dict(streams=2, stag=1, persist=0), dict(streams=2, stag=1), dict(streams=2, stag=2), dict(streams=1, stag=2), dict(streams=1, stag=1)]:
         safe(timing, sd, 224, 224, 256, "f16", opts)
     safe(timing, sd, 224, 224, 256, "bf16", dict(patch=1, bm256=1))
     safe(timing, sd, 512, 512, 64, "f16", dict(patch=1, bm256=1), iters=5)
