@@ -46,6 +46,19 @@ template <typename T> __device__ __forceinline__ float unpack_hi(unsigned w) {
   return to_f32<T>(__builtin_bit_cast(T, (unsigned short)(w >> 16)));
 }
 
+// Packed 16-bit helpers on raw f16 / bf16 bit patterns (two values per 32-bit word):
+//   ReLU  = signed-integer max with 0  (a negative float has its sign bit set, -0.0 becomes +0.0)
+//   max of NON-NEGATIVE values = unsigned-integer max (IEEE ordering of same-sign values is the bit ordering)
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_relu16(unsigned a) {
+  const i16x2_t z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, a), z));
+}
+__device__ __forceinline__ unsigned pk_max16_nonneg(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+
 // Bijective XCD-aware block remap (blocks b and b+8 share an XCD under the
 // observed round-robin dispatch; speed only, never correctness): each XCD gets a
 // contiguous run of logical tile ids so tiles that share halo rows / weight

@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   {
     constexpr int NI = (PR * PC + 255) / 256;                 // 7
     float v0[NI], v1[NI], v2[NI];
-    size_t off[NI];
+    int off[NI];                                              // element offset inside this image (< 2^31)
     bool ok[NI];
+    const int estep = p.in_format == 0 ? 1 : 3;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int i = tid + k * 256;
@@ -76,22 +77,23 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
       const int y = py0 + r, x = px0 + c;
       ok[k] = i < PR * PC && y >= 0 && y < p.H && x >= 0 && x < p.W;
       const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);   // always a legal address
-      off[k] = p.in_format == 0 ? ((size_t)img * 3 * p.H + yc) * p.W + xc : (((size_t)img * p.H + yc) * p.W + xc) * 3;
+      off[k] = (yc * p.W + xc) * estep;
     }
+    const size_t img_elems = (size_t)3 * p.H * p.W;
     if (p.in_format == 0) {
-      const float* s = (const float*)p.x;
-      const size_t plane = (size_t)p.H * p.W;
+      const float* s = (const float*)p.x + (size_t)img * img_elems;
+      const int plane = p.H * p.W;
 #pragma unroll
       for (int k = 0; k < NI; ++k) { v0[k] = s[off[k]]; v1[k] = s[off[k] + plane]; v2[k] = s[off[k] + 2 * plane]; }
     } else if (p.in_format == 3) {
-      const unsigned char* s = (const unsigned char*)p.x;
+      const unsigned char* s = (const unsigned char*)p.x + (size_t)img * img_elems;
       unsigned char a[NI], b[NI], c[NI];
 #pragma unroll
       for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; c[k] = s[off[k] + 2]; }
 #pragma unroll
       for (int k = 0; k < NI; ++k) { v0[k] = (float)a[k] / 255.0f; v1[k] = (float)b[k] / 255.0f; v2[k] = (float)c[k] / 255.0f; }
     } else {
-      const unsigned short* s = (const unsigned short*)p.x;
+      const unsigned short* s = (const unsigned short*)p.x + (size_t)img * img_elems;
       unsigned short a[NI], b[NI], c[NI];
 #pragma unroll
       for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; c[k] = s[off[k] + 2]; }
@@ -134,11 +136,16 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   }
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;       // 64-byte weight rows: slot g at g ^ h[(r>>2)&3]
   const int wo_ = r16 * 64 + ((g ^ wsw) << 4);
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NT];                                      // accumulators start at the folded-BN bias
+  {
+    f32x4 b4[NT];
 #pragma unroll
-  for (int pt = 0; pt < MT; ++pt)
+    for (int ct = 0; ct < NT; ++ct) b4[ct] = *(const f32x4*)(p.bias + g * 16 + ct * 4);
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
+  }
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky) {
     frag wf[NT], xf[MT];
@@ -153,28 +160,28 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   }
   __syncthreads();                                          // everyone is done reading Ws / Ps
 
-  // ---- bias + ReLU -> Cs (positions outside the conv output are 0: neutral for a max of ReLU values)
+  // ---- ReLU -> Cs, packed (cvt_pk + one v_pk_max_i16 per channel pair).  Conv positions outside the feature
+  // map (only the -1 row / column of top / left tiles, or the tail of a ragged last tile) are forced to 0:
+  // neutral for a max over ReLU outputs.  The test is wave-uniform per block edge, so interior tiles skip it.
   {
-    float bias[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) bias[i] = p.bias[g * 16 + i];
+    const bool edge = cr0 < 0 || cc0 < 0 || cr0 + CR > p.Hs || cc0 + CR > p.Ws;
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
       const int q = qidx[pt];
       if (q >= 0) {
-        const int qr = q / CR, qc = q - qr * CR;
-        const int cr = cr0 + qr, cc = cc0 + qc;
-        const bool inside = cr >= 0 && cr < p.Hs && cc >= 0 && cc < p.Ws;
         u32x4 o[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int w2 = 0; w2 < 4; ++w2) {
             const int c = h * 8 + w2 * 2;                   // channel pair c, c+1 of this lane's 16
-            const float v0 = inside ? fmaxf(acc[pt][c >> 2][c & 3] + bias[c], 0.f) : 0.f;
-            const float v1 = inside ? fmaxf(acc[pt][(c + 1) >> 2][(c + 1) & 3] + bias[c + 1], 0.f) : 0.f;
-            o[h][w2] = pack2<T>(v0, v1);
+            o[h][w2] = pk_relu16(pack2<T>(acc[pt][c >> 2][c & 3], acc[pt][(c + 1) >> 2][(c + 1) & 3]));
           }
+        if (edge) {
+          const int qr = q / CR, qc = q - qr * CR;
+          const int cr = cr0 + qr, cc = cc0 + qc;
+          if (!(cr >= 0 && cr < p.Hs && cc >= 0 && cc < p.Ws)) { o[0] = u32x4{0u, 0u, 0u, 0u}; o[1] = o[0]; }
+        }
         // row q, 16-byte slots 2g and 2g+1, stored at slot ^ (q & 7)
         *(u32x4*)(Cs + q * 128 + (((2 * g) ^ (q & 7)) << 4)) = o[0];
         *(u32x4*)(Cs + q * 128 + (((2 * g + 1) ^ (q & 7)) << 4)) = o[1];
@@ -189,9 +196,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
     const int pr = pp >> 3, pc = pp & 7;
     const int oy = ty * 8 + pr, ox = tx * 8 + pc;
     if (oy >= p.Hq || ox >= p.Wq) continue;
-    float m[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m[k] = 0.f;
+    u32x4 o = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -199,14 +204,8 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
         const int q = (2 * pr + dy) * CR + 2 * pc + dx;
         const u32x4 v = *(const u32x4*)(Cs + q * 128 + ((cg ^ (q & 7)) << 4));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          m[2 * k] = fmaxf(m[2 * k], unpack_lo<T>(v[k]));
-          m[2 * k + 1] = fmaxf(m[2 * k + 1], unpack_hi<T>(v[k]));
-        }
+        for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
       }
-    u32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = pack2<T>(m[2 * k], m[2 * k + 1]);
     char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
     *(u32x4*)dst = o;
   }

@@ -87,7 +87,7 @@ def main():
             safe(parity, sd, 96, 80, 3, dtype, opts)
             if not quick:
                 safe(parity, sd, 224, 224, 5, dtype, opts)
-    for opts in [dict(streams=2, stag=1, persist=0), dict(streams=2, stag=1), dict(streams=2, stag=2), dict(streams=1, stag=2), dict(streams=1, stag=1)]:
+    for opts in [dict(streams=2, stag=1, persist=0), dict(streams=2, stag=2, persist=0), dict(streams=2, stag=2, persist=1), dict(streams=1, stag=2, persist=1), dict(streams=3, stag=1, persist=0)]:
         safe(timing, sd, 224, 224, 256, "f16", opts)
     safe(timing, sd, 224, 224, 256, "bf16", dict(patch=1, bm256=1))
     safe(timing, sd, 512, 512, 64, "f16", dict(patch=1, bm256=1), iters=5)
