@@ -84,21 +84,33 @@ extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream) {
 // One block per image; thread t sums channel pair (2t, 2t+1) when 16-bit.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_kernel(const void* in, float* out, int h, int w, int C) {
+  // one block per image; thread = (pixel group pg of 4, channel pair c2 of 64 per pass): the h*w pixels are
+  // strided over the 4 groups so four times as many independent 4-byte loads are in flight per channel
+  __shared__ float red[4][128];
   const int b = blockIdx.x;
-  const int Wp = w + 2;
-  const float inv = 1.f / (float)(h * w);
-  for (int c2 = threadIdx.x; c2 < C / 2; c2 += 256) {
+  const int Wp = w + 2, npx = h * w;
+  const float inv = 1.f / (float)npx;
+  const int pg = threadIdx.x >> 6, cl = threadIdx.x & 63;
+  for (int c0 = 0; c0 < C / 2; c0 += 64) {
+    const int c2 = c0 + cl;
     float s0 = 0.f, s1 = 0.f;
-    for (int y = 0; y < h; ++y) {
-      const unsigned* row = (const unsigned*)((const char*)in + ((((size_t)b * (h + 2) + y + 1) * Wp + 1) * C) * 2) + c2;
-      for (int x = 0; x < w; ++x) {
-        const unsigned v = row[(size_t)x * (C / 2)];
+    if (c2 < C / 2) {
+      const unsigned* base = (const unsigned*)((const char*)in + (size_t)b * (h + 2) * Wp * C * 2) + c2;
+#pragma unroll 4
+      for (int i = pg; i < npx; i += 4) {
+        const int y = i / w, x = i - y * w;
+        const unsigned v = base[(size_t)((y + 1) * Wp + x + 1) * (C / 2)];
         s0 += unpack_lo<T>(v);
         s1 += unpack_hi<T>(v);
       }
     }
-    out[(size_t)b * C + 2 * c2] = s0 * inv;
-    out[(size_t)b * C + 2 * c2 + 1] = s1 * inv;
+    red[pg][cl * 2] = s0; red[pg][cl * 2 + 1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 128 && c0 * 2 + (int)threadIdx.x < C) {
+      const int t = threadIdx.x;
+      out[(size_t)b * C + c0 * 2 + t] = (red[0][t] + red[1][t] + red[2][t] + red[3][t]) * inv;
+    }
+    __syncthreads();
   }
 }
 
@@ -132,39 +144,43 @@ extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, in
 __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ feat, const float* __restrict__ W1,
                                                   const float* __restrict__ b1, float* __restrict__ hidden,
                                                   int B, int K, int N) {
+  // one wave = 16 outputs x 32 images (two MFMA column tiles); N/16 * B/32 waves keep every CU busy
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   const int ntile = blockIdx.x * 4 + wave;
   const int n0 = ntile * 16;
-  const int img0 = blockIdx.y * 64;
+  const int img0 = blockIdx.y * 32;
   if (n0 >= N) return;
   const float* wrow = W1 + (size_t)(n0 + r16) * K + 4 * g;
-  const float* frow[4];
+  const float* frow[2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) frow[t] = feat + (size_t)min(img0 + t * 16 + r16, B - 1) * K + 4 * g;
-  f32x4 acc[4];
+  for (int t = 0; t < 2; ++t) frow[t] = feat + (size_t)min(img0 + t * 16 + r16, B - 1) * K + 4 * g;
+  f32x4 acc[2][2];                                          // [image tile][K parity]: 4 independent chains
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    const f32x4 a = *(const f32x4*)(wrow + k0);
-    f32x4 bv[4];
+  for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+#pragma unroll 2
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const f32x4 a0 = *(const f32x4*)(wrow + k0), a1 = *(const f32x4*)(wrow + k0 + 16);
+    f32x4 f0[2], f1[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bv[t] = *(const f32x4*)(frow[t] + k0);
+    for (int t = 0; t < 2; ++t) { f0[t] = *(const f32x4*)(frow[t] + k0); f1[t] = *(const f32x4*)(frow[t] + k0 + 16); }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bv[t][s], acc[t], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], f0[t][s], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], f1[t][s], acc[t][1], 0, 0, 0);
+      }
   }
   // D: col = lane&15 = image, row = 4*(lane>>4)+reg = output n
   const f32x4 bias = *(const f32x4*)(b1 + n0 + 4 * g);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < 2; ++t) {
     const int img = img0 + t * 16 + r16;
     if (img < B) {
       f32x4 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = fmaxf(acc[t][q] + bias[q], 0.f);
+      for (int q = 0; q < 4; ++q) o[q] = fmaxf(acc[t][0][q] + acc[t][1][q] + bias[q], 0.f);
       *(f32x4*)(hidden + (size_t)img * N + n0 + 4 * g) = o;
     }
   }
@@ -184,8 +200,8 @@ __global__ __launch_bounds__(256) void fc1_simple_kernel(const float* feat, cons
 extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* b1, float* hidden, int B, int K,
                                 int N, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (K % 16 == 0 && N % 16 == 0) {
-    const dim3 grid((N / 16 + 3) / 4, (B + 63) / 64);
+  if (K % 32 == 0 && N % 16 == 0) {
+    const dim3 grid((N / 16 + 3) / 4, (B + 31) / 32);
     hipLaunchKernelGGL(fc1_kernel, grid, dim3(256), 0, st, feat, W1, b1, hidden, B, K, N);
   } else {
     const size_t total = (size_t)B * N;
@@ -208,13 +224,14 @@ __global__ __launch_bounds__(256) void fc2_procrustes_kernel(const float* __rest
   for (int j = 0; j < 9; ++j) acc[j] = 0.f;
   const float* h = hidden + (size_t)img * K;
   if ((K & 3) == 0) {
+#pragma unroll 2
     for (int k = lane * 4; k < K; k += 256) {
       const f32x4 hv = *(const f32x4*)(h + k);
+      f32x4 wv[9];
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const f32x4 wv = *(const f32x4*)(W2 + (size_t)j * K + k);
-        acc[j] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
-      }
+      for (int j = 0; j < 9; ++j) wv[j] = *(const f32x4*)(W2 + (size_t)j * K + k);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[j] += hv[0] * wv[j][0] + hv[1] * wv[j][1] + hv[2] * wv[j][2] + hv[3] * wv[j][3];
     }
   } else {
     for (int k = lane; k < K; k += 64)
