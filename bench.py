@@ -163,6 +163,15 @@ def main():
                            "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                            "gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2),
                            "step_frac_of_peak": round(value / world * eng.flops(1) / 1e12 / PEAK_TFLOPS, 4)}
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure is the committed rocprofv3 --pmc result for this same workload (profiles/r01_traffic.json)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(dom)
+            if tr and (B, S, args.dtype) == (256, 224, "f16"):
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+        except (OSError, ValueError, KeyError):
+            pass
         out["kernels_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
         # ---- parity of this very configuration against the oracle on a sample ---------------------
         from oracle import posenet_ref as O

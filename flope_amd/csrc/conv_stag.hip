@@ -136,11 +136,11 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   } while (0)
 
   frag wf[2][NT], xf[2][MT];
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NT];                                       // start at the folded-BN bias: no bias add in the epilogue
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
 
   // fragment reads of one double step: ring slot, patch buffers and taps are literals
 #define LOADF(slot_, buf0_, tap0_, buf1_, tap1_)                                                               \
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q] + bias[ct * 4 + q];
+          for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
         if constexpr (RES) {
 #pragma unroll
           for (int c = 0; c < 2; ++c)
@@ -272,22 +272,21 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
               v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[pt][c][q]);
             }
         }
-        if (p.relu) {
-#pragma unroll
-          for (int i = 0; i < NT * 4; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
         if (ok[pt]) {
           char* op = (char*)p.out + ooff[pt];
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             u32x4 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
+            for (int q = 0; q < 4; ++q) {
+              const unsigned w_ = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
+              o[q] = p.relu ? pk_relu16(w_) : w_;            // ReLU on the packed pair: one op per two channels
+            }
             *(u32x4*)(op + c * 16) = o;
           }
         }
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
       }
     }
     if (!has_next) break;
