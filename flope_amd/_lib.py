@@ -39,6 +39,13 @@ SIGNATURES = {
     "flope_launch_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_D)]),
     "flope_describe_plan": (_I, [_P, C.c_char_p, _I]),
     "flope_version": (C.c_char_p, []),
+    "flope_tf_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "flope_tf_destroy": (_I, [_P]),
+    "flope_tf_last_error": (C.c_char_p, [_P]),
+    "flope_tf_load_weights": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_I), C.POINTER(_P)]),
+    "flope_tf_forward": (_I, [_P, _P, _I, _I, _P, _P]),
+    "flope_tf_set_option": (_I, [_P, C.c_char_p, _I]),
+    "flope_tf_forward_flops": (_D, [_P, _I, _I]),
 }
 
 _lib = None

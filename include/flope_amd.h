@@ -149,6 +149,34 @@ int flope_describe_plan(flope_handle h, char* buf, int buflen);
 /* library / build identification */
 const char* flope_version(void);
 
+/* ---- TransformerEncoder (reference scripts/tf_encoder.py:5-27) -------------
+ * Replaces `TransformerEncoder(input_dim, model_dim, out_dim, num_heads, num_layers, ff_dim,
+ * dropout)` + `.load_state_dict()` + `forward(x)` in eval mode (dropout = identity):
+ *   embedding Linear -> num_layers x post-norm nn.TransformerEncoderLayer (ReLU, batch_first,
+ *   no mask, no positional encoding) -> out_layer Linear.
+ * dtype FLOPE_DT_F32: fp32 everywhere (any dimensions).  FLOPE_DT_F16 / BF16: 16-bit activations,
+ * fp32 accumulation; linears with N % 128 == 0 and K % 64 == 0 and attention with head_dim 64
+ * (seq_len <= 512) run on MFMA, everything else on generic kernels.
+ * max_tokens bounds batch*seq_len of any later forward.  Same ownership / error rules as above. */
+typedef struct flope_tf_encoder* flope_tf_handle;
+int flope_tf_create(int device_id, int input_dim, int model_dim, int out_dim, int num_heads,
+                    int num_layers, int ff_dim, int max_tokens, int dtype, flope_tf_handle* out);
+int flope_tf_destroy(flope_tf_handle h);
+const char* flope_tf_last_error(flope_tf_handle h);
+/* names as in the reference module's state_dict(): embedding.{weight,bias},
+ * transformer_encoder.layers.<i>.{self_attn.in_proj_weight, self_attn.in_proj_bias,
+ * self_attn.out_proj.{weight,bias}, linear1.*, linear2.*, norm1.*, norm2.*}, out_layer.* */
+int flope_tf_load_weights(flope_tf_handle h, int n, const char* const* names,
+                          const float* const* host_ptrs, const int* ndims,
+                          const int64_t* const* shapes);
+/* x_dev float32 [batch, seq_len, input_dim] -> y_dev float32 [batch, seq_len, out_dim] */
+int flope_tf_forward(flope_tf_handle h, const float* x_dev, int batch, int seq_len, float* y_dev,
+                     void* stream);
+/* "generic" = 1 forces the generic kernels (A/B checks); returns previous value or <0 */
+int flope_tf_set_option(flope_tf_handle h, const char* name, int value);
+/* algorithmic FLOPs of one forward (2*MAC: linears + QK^T + PV) */
+double flope_tf_forward_flops(flope_tf_handle h, int batch, int seq_len);
+
 #ifdef __cplusplus
 }
 #endif

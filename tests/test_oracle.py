@@ -133,3 +133,32 @@ def test_fold_bn_equals_bn(state_dict):
     y1 = torch.nn.functional.conv2d(x, w, b, padding=1)
     y2 = O._bn(torch.nn.functional.conv2d(x, sd["base.layer1.0.conv1.weight"], None, padding=1), sd, "base.layer1.0.bn1")
     np.testing.assert_allclose(y1.numpy(), y2.numpy(), atol=2e-5)
+
+
+# ---- TransformerEncoder oracle: pinned by the output of the reference module itself --------------
+def _tf_sd(ref_fixtures):
+    return {k[len("tf_sd::"):]: v for k, v in ref_fixtures.items() if k.startswith("tf_sd::")}
+
+
+def test_tf_encoder_oracle_matches_reference_fixture(ref_fixtures):
+    from oracle import tf_encoder_ref as T
+    sd = _tf_sd(ref_fixtures)
+    assert sorted(sd) == sorted(T.expected_keys(2))
+    y = T.forward(sd, ref_fixtures["tf_x"], num_heads=4)
+    assert y.shape == (8, 10, 9)
+    assert np.abs(y - ref_fixtures["tf_y"]).max() < 2e-6          # fp64 restatement vs the reference's fp32 run
+    y32 = T.forward(sd, ref_fixtures["tf_x"], num_heads=4, dtype=np.float32)
+    assert np.abs(y32 - ref_fixtures["tf_y"]).max() < 5e-6
+
+
+def test_tf_encoder_oracle_properties():
+    from oracle import tf_encoder_ref as T
+    sd = T.synthetic_state_dict(16, 64, 9, 2, 128, seed=3)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 7, 16))
+    y = T.forward(sd, x, num_heads=2)
+    # no positional encoding and no mask: permuting the tokens of a sequence permutes the outputs
+    perm = rng.permutation(7)
+    assert np.allclose(T.forward(sd, x[:, perm], num_heads=2), y[:, perm], atol=1e-10)
+    # sequences of a batch are independent
+    assert np.allclose(T.forward(sd, x[1:2], num_heads=2), y[1:2], atol=1e-10)
