@@ -31,3 +31,13 @@ def get_pose_mat(trans_rot):
     pose[:, :3, 3] = tr[:, :3]
     pose[:, :3, :3] = tr[:, 3:].reshape(-1, 3, 3)
     return pose
+
+
+def qvec2rotmat(quat):
+    """scalar-last quaternion(s) [x,y,z,w] -> rotation matrix/matrices (reference conversion.py:37-38)"""
+    return _Rot.from_quat(quat).as_matrix()
+
+
+def rotmat2qvec(rotmat):
+    """rotation matrix/matrices -> scalar-last quaternion(s) [x,y,z,w] (reference conversion.py:41-42)"""
+    return _Rot.from_matrix(rotmat).as_quat()

@@ -209,6 +209,23 @@ def test_depth_lift_vs_oracle():
     assert r2.tolist() == rel_ref.tolist()
 
 
+def test_depth_val_file_rows_vs_oracle(tmp_path):
+    """scripts/extract_depth.py:25-57 -> the 2 x N depth_val file, and its round trip into the fusion step."""
+    from flope_amd.harness import depth_val_rows, write_depth_val_file
+    rgb, mask, depth, boxes = _scene(23)
+    dv_ref, rel_ref = P.get_depth_value(boxes, depth.astype(np.float32) / 1000, mask, near_plane=0.1, far_plane=3.0)
+    rows = depth_val_rows(depth, mask, boxes, depth_div=1000.0, near=0.1, far=3.0)
+    assert rows.shape == (2, len(boxes)) and rows.dtype == np.float64
+    np.testing.assert_allclose(rows[0], dv_ref, atol=1e-5)
+    assert (rows[1] > 0.5).tolist() == rel_ref.tolist()
+    write_depth_val_file(tmp_path / "d.txt", rows)
+    np.testing.assert_allclose(np.loadtxt(tmp_path / "d.txt"), rows)
+    assert depth_val_rows(depth, mask, np.zeros((0, 4))).shape == (0,)
+    # float32 metre depth (the script's 'npy' branch) gives the same numbers
+    rows_f = depth_val_rows(depth.astype(np.float32) / 1000, mask, boxes, near=0.1, far=3.0)
+    np.testing.assert_allclose(rows_f[0], dv_ref, atol=1e-5)
+
+
 def test_fast_pose_predictor_end_to_end_vs_oracle(state_dict, tmp_path):
     """BASELINE cfg3 (detections given): frame -> boxes+mask -> crop -> PoseNet -> Procrustes -> yaw-null -> Rt."""
     import yaml
