@@ -176,11 +176,40 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
   LANE_SETUP();
 
+  // ---- residual of the FIRST tile: loaded before anything else (oldest VM ops, so the wait below covers them) and
+  // folded into the accumulators while the first patch / weight tiles are still in flight -- with one workgroup
+  // per CU nothing else would hide that latency at the kernel's tail.  Later tiles of a persistent grid load
+  // theirs in the epilogue.
+  bool res_pre = RES;
+  u32x4 rpre[RES ? MT : 1][2];
+  if constexpr (RES) {
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) {
+      const int mc = min(m0 + group * GP + wpx * 64 + pt * 16 + pcol, mend - 1);
+      const int b_ = fastdiv(mc, p.mg_hw, p.sh_hw), r_ = mc - b_ * HoWo;
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+      const char* rp = (const char*)p.res + ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + cb) * 2;
+      rpre[pt][0] = *(const u32x4*)rp;
+      rpre[pt][1] = *(const u32x4*)(rp + 16);
+    }
+  }
   // ---- prologue: patch of half-chunk 0, double tiles 0 and 1
   ISSUE_PATCH(patch_src, 0);
   ISSUE_DT(0, 0);
   ISSUE_DT(1, 1);
   WAIT_VM(TG);                                 // patch 0 and double tile 0 landed (double tile 1 may fly)
+  if constexpr (RES) {
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = ct * 4 + q;
+          const unsigned w_ = rpre[pt][i >> 3][(i & 7) >> 1];
+          acc[pt][ct][q] += (i & 1) ? unpack_hi<T>(w_) : unpack_lo<T>(w_);
+        }
+  }
   BARRIER();
   if (group == 1) BARRIER();                   // group B runs one phase behind group A
 
@@ -249,11 +278,13 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       // all residual loads first (one latency, not one per pixel tile), then compute + store
       u32x4 rv[RES ? MT : 1][2];
       if constexpr (RES) {
+        if (!res_pre) {
 #pragma unroll
-        for (int pt = 0; pt < MT; ++pt) {
-          const char* rp = (const char*)p.res + ooff[pt];
-          rv[pt][0] = *(const u32x4*)rp;
-          rv[pt][1] = *(const u32x4*)(rp + 16);
+          for (int pt = 0; pt < MT; ++pt) {
+            const char* rp = (const char*)p.res + ooff[pt];
+            rv[pt][0] = *(const u32x4*)rp;
+            rv[pt][1] = *(const u32x4*)(rp + 16);
+          }
         }
       }
 #pragma unroll
@@ -264,13 +295,15 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
         if constexpr (RES) {
+          if (!res_pre) {
 #pragma unroll
-          for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              v[c * 8 + q * 2] += unpack_lo<T>(rv[pt][c][q]);
-              v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[pt][c][q]);
-            }
+              for (int q = 0; q < 4; ++q) {
+                v[c * 8 + q * 2] += unpack_lo<T>(rv[pt][c][q]);
+                v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[pt][c][q]);
+              }
+          }
         }
         if (ok[pt]) {
           char* op = (char*)p.out + ooff[pt];
@@ -298,11 +331,12 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     LANE_SETUP();
     dn -= ND;
     hc = 0;
-    if (full_tile) {
+    if (full_tile && !res_pre) {
       after_epi = true;                        // the epilogue issued exactly EPI_OPS VM ops per lane
     } else {
-      WAIT_VM(0);                              // partial tile: op count unknown -> drain once, static counts stay valid
+      WAIT_VM(0);                              // partial / first residual tile: op count differs -> drain once, static counts stay valid
     }
+    res_pre = false;
   }
   if (group == 0) BARRIER();                                // every wave executes the same number of barriers
   WAIT_VM(0);                                               // drain the wrapped-around tail DMAs before LDS is released
