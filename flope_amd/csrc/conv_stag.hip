@@ -39,7 +39,13 @@ __device__ __forceinline__ int tile_px_s(int c) { return c < 4 ? 2 * c : (c < 12
 // continues across a tile boundary: the weight ring wraps to the panel's first tiles and the last half-chunk's
 // patch burst fetches the NEXT tile's first patch, so no DMA latency is ever re-exposed; only the register
 // epilogue + the next tile's address table sit between two tiles (one group at a time, the other keeps going).
-template <typename T, int PT, int BN, bool RES>
+// ROWS (layer 1, Wo <= 64, Ho % 8 == 0): a tile is 8 full output rows of ONE image, wave (group, wpx) owns row
+// group*4 + wpx and its four pixel tiles are columns 0..63 of that row (columns >= Wo are computed and dropped).
+// Every tile then has the same geometry relative to its patch origin: the fragment address table is built once
+// per workgroup instead of once per tile (it was ~300 of the ~1000 vector instructions a tile cost outside its
+// MFMAs -- with K = 576 those instructions were as expensive as the 288 MFMAs), 7 tiles per image divide the
+// 256 x 7 tiles of B = 256 evenly over 256 CUs, and m0 carries the tile's first padded OUTPUT row.
+template <typename T, int PT, int BN, bool RES, bool ROWS>
 __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
   constexpr int BM = BN == 128 ? 256 : 512, GP = BM / 2, TILE_B = BN * 64;   // 8 / 4 KB weight tile per (half-chunk, tap)
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   constexpr int TG = DT_B / 8192;                           // LDS-DMA ops per wave per double tile (2 / 1)
   constexpr int MT = 4, NT = 4;
   constexpr int PATCH_B = PT * 8192;                              // bytes of one patch buffer
-  constexpr int EPI_OPS = MT * 2 + (RES ? MT * 2 : 0);            // 16-byte stores (+ residual loads) per lane per tile
+  constexpr int EPI_OPS = MT * 2 + ((RES && !ROWS) ? MT * 2 : 0);  // 16-byte stores (+ residual loads, unless prefetched: ROWS) per lane per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;                                   // 2 patch buffers (first: their offsets stay ds_read immediates)
   char* const Bs = smem + 2 * PATCH_B;                     // NBD double-tile weight ring
@@ -98,21 +104,36 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   bool has_next;
 #define TILE_GEOM(tile_, m0_, mend_, R0_, src_)                                                                \
   do {                                                                                                         \
-    m0_ = ((tile_) / p.ntiles) * BM;                                                                           \
-    mend_ = min(m0_ + BM, p.M);                                                                                \
-    const int b0_ = fastdiv(m0_, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0_ - b0_ * HoWo, p.mg_w, p.sh_w);          \
-    R0_ = b0_ * p.Hip + ho0_;                                                                                  \
+    if constexpr (ROWS) {                                                                                      \
+      const int b0_ = (tile_) / p.tiles_per_image, j0_ = (tile_) - b0_ * p.tiles_per_image;                    \
+      m0_ = b0_ * p.Hop + j0_ * 8;                                                                             \
+      mend_ = m0_ + BM;                                                                                        \
+      R0_ = b0_ * p.Hip + j0_ * 8;                                                                             \
+    } else {                                                                                                   \
+      m0_ = ((tile_) / p.ntiles) * BM;                                                                         \
+      mend_ = min(m0_ + BM, p.M);                                                                              \
+      const int b0_ = fastdiv(m0_, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0_ - b0_ * HoWo, p.mg_w, p.sh_w);        \
+      R0_ = b0_ * p.Hip + ho0_;                                                                                \
+    }                                                                                                          \
     src_ = (const char*)p.in + (size_t)R0_ * rowB;                                                             \
   } while (0)
-  int xoff[9][MT];
+  // ROWS: the four pixel tiles of a wave are 16 pixels apart in one row -> same swizzle term, offsets differ by
+  // 16 * 64 B, which folds into the ds_read immediate: 9 address registers instead of 36
+  int xoff[9][ROWS ? 1 : MT];
+#define XO(t_, pt_) (ROWS ? xoff[t_][0] + (pt_) * 1024 : xoff[t_][ROWS ? 0 : (pt_)])
 #define LANE_SETUP()                                                                                           \
   do {                                                                                                         \
-    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
-      const int mm_ = m0 + group * GP + wpx * 64 + pt * 16 + pcol;                                             \
-      const int m_ = min(mm_, mend - 1);                                                                       \
-      const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - b_ * HoWo;                                       \
-      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;                                      \
-      const int pi0_ = (b_ * p.Hip + ho_ - R0) * p.Wip + wo_;                                                  \
+    _Pragma("unroll") for (int pt = 0; pt < (ROWS ? 1 : MT); ++pt) {                                           \
+      int pi0_;                                                                                                \
+      if constexpr (ROWS) {                                                                                    \
+        pi0_ = (group * 4 + wpx) * p.Wip + pcol;                                                               \
+      } else {                                                                                                 \
+        const int mm_ = m0 + group * GP + wpx * 64 + pt * 16 + pcol;                                           \
+        const int m_ = min(mm_, mend - 1);                                                                     \
+        const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - b_ * HoWo;                                     \
+        const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;                                    \
+        pi0_ = (b_ * p.Hip + ho_ - R0) * p.Wip + wo_;                                                          \
+      }                                                                                                        \
       _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                          \
         const int pi = pi0_ + (t / 3) * p.Wip + (t % 3);                                                       \
         xoff[t][pt] = (pi << 6) + ((g ^ ((pi >> 2) & 3)) << 4);                                                \
@@ -150,8 +171,8 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       wf[1][ct] = *(const frag*)(smem + wbase + (slot_) * DT_B + TILE_B + ct * 1024);                          \
     }                                                                                                          \
     _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
-      xf[0][pt] = *(const frag*)(smem + xoff[tap0_][pt] + (buf0_) * PATCH_B);                                  \
-      xf[1][pt] = *(const frag*)(smem + xoff[tap1_][pt] + (buf1_) * PATCH_B);                                  \
+      xf[0][pt] = *(const frag*)(smem + XO(tap0_, pt) + (buf0_) * PATCH_B);                                    \
+      xf[1][pt] = *(const frag*)(smem + XO(tap1_, pt) + (buf1_) * PATCH_B);                                    \
     }                                                                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
   } while (0)
@@ -169,6 +190,25 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       GLDS16(b_base + (size_t)(dt_) * DT_B + o * 8192 + lane16, Bs + (slot_) * DT_B + o * 8192 + wave * 1024); \
   } while (0)
 
+  // byte offset of this lane's 16 channels of pixel tile pt in the padded NHWC output (clamped to a legal pixel)
+  auto rows_off = [&](int rowbase, int pt) -> size_t {      // ROWS: rowbase = the tile's first padded output row
+    const int col = min(pt * 16 + pcol, p.Wo - 1);
+    return ((((size_t)(rowbase + group * 4 + wpx + 1)) * p.Wop + col + 1) * p.Cout + cb) * 2;
+  };
+  auto out_off = [&](int pt, bool& valid) -> size_t {
+    if constexpr (ROWS) {
+      valid = pt * 16 + pcol < p.Wo;
+      return rows_off(m0, pt);
+    } else {
+      const int mm = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
+      valid = mm < mend;
+      const int mc = min(mm, mend - 1);
+      const int b_ = fastdiv(mc, p.mg_hw, p.sh_hw), r_ = mc - b_ * HoWo;
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+      return ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + cb) * 2;
+    }
+  };
+
   // ---- first tile of this workgroup + the one after it
   int tile = lb;
   TILE_GEOM(tile, m0, mend, R0, patch_src);
@@ -185,10 +225,8 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   if constexpr (RES) {
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
-      const int mc = min(m0 + group * GP + wpx * 64 + pt * 16 + pcol, mend - 1);
-      const int b_ = fastdiv(mc, p.mg_hw, p.sh_hw), r_ = mc - b_ * HoWo;
-      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
-      const char* rp = (const char*)p.res + ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + cb) * 2;
+      bool v_;
+      const char* rp = (const char*)p.res + out_off(pt, v_);
       rpre[pt][0] = *(const u32x4*)rp;
       rpre[pt][1] = *(const u32x4*)(rp + 16);
     }
@@ -229,6 +267,14 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   // Younger VM ops than double tile D+1 at the wait: the TG ops of double tile D+2, plus the PT patch rounds
   // when a burst was issued at double step D-1 or D (D in {0,1,5,6}), plus -- at D = 0 right after a tile
   // boundary -- the EPI_OPS stores / residual loads of the epilogue that ran in between.
+  // timing experiments only (build with -DFLOPE_STAG_DBG; results are wrong by construction):
+  //   1 no weight DMA, 2 no patch refills, 4 no MFMA, 16 no LDS reads, 32 no stores
+#ifdef FLOPE_STAG_DBG
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+  u32x4 rq[(RES && ROWS) ? MT : 1][2];                      // ROWS + RES: next tile's residual, in flight from double step 6
   int dn = 2;                                               // double tile to issue at the start of the next double step
   int hc = 0;                                               // first half-chunk of the current body
   bool after_epi = false;
@@ -236,22 +282,31 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #define DSTEP(D)                                                                                               \
   do {                                                                                                         \
     constexpr int U0_ = 2 * (D), U1_ = 2 * (D) + 1;                                                            \
-    constexpr int WN_ = TG + (((D) == 0 || (D) == 1 || (D) == 5 || (D) == 6) ? PT : 0);                        \
-    {                                                                                                          \
+    constexpr int WN_ = TG + (((D) == 0 || (D) == 1 || (D) == 5 || (D) == 6) ? PT : 0) +                       \
+                        ((RES && ROWS && ((D) == 6 || (D) == 7)) ? 2 * MT : 0);                                \
+    if (!(dbg & 1)) {                                                                                          \
       const int di_ = dn < ND ? dn : dn - ND;                                                                  \
       ISSUE_DT(di_, ((D) + 2) % NBD);                                                                          \
-      ++dn;                                                                                                    \
     }                                                                                                          \
-    if ((D) == 0) ISSUE_PATCH(patch_src + (hc + 1) * 64, 1);                                                   \
-    if ((D) == 5) {                                                                                            \
+    ++dn;                                                                                                      \
+    if ((D) == 0 && !(dbg & 2)) ISSUE_PATCH(patch_src + (hc + 1) * 64, 1);                                     \
+    if ((D) == 5 && !(dbg & 2)) {                                                                              \
       const char* s_ = hc + 2 < nhc ? patch_src + (hc + 2) * 64 : (has_next ? n_patch_src : patch_src);        \
       ISSUE_PATCH(s_, 0);                                                                                      \
     }                                                                                                          \
-    LOADF((D) % NBD, U0_ / 9, U0_ % 9, U1_ / 9, U1_ % 9);                                                      \
-    if ((D) == 0 && after_epi) WAIT_VM(WN_ + EPI_OPS);                                                         \
+    if constexpr (RES && ROWS && (D) == 6) {   /* residual of the NEXT tile (of this one again at the very end) */ \
+      _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                      \
+        const char* rp_ = (const char*)p.res + rows_off(has_next ? n_m0 : m0, pt);                             \
+        rq[pt][0] = *(const u32x4*)rp_;                                                                        \
+        rq[pt][1] = *(const u32x4*)(rp_ + 16);                                                                 \
+      }                                                                                                        \
+    }                                                                                                          \
+    if (!(dbg & 16)) LOADF((D) % NBD, U0_ / 9, U0_ % 9, U1_ / 9, U1_ % 9);                                     \
+    if (dbg & 3) WAIT_VM(0);                                                                                   \
+    else if ((D) == 0 && after_epi) WAIT_VM(WN_ + EPI_OPS);                                                    \
     else WAIT_VM(WN_);                                                                                         \
     BARRIER();                                                                                                 \
-    MFMAS();                                                                                                   \
+    if (!(dbg & 4)) MFMAS();                                                                                   \
     BARRIER();                                                                                                 \
   } while (0)
 
@@ -267,17 +322,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       size_t ooff[MT];
       bool ok[MT];
 #pragma unroll
-      for (int pt = 0; pt < MT; ++pt) {
-        const int mm = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
-        ok[pt] = mm < mend;
-        const int mc = min(mm, mend - 1);                    // clamped: loads below are always legal
-        const int b_ = fastdiv(mc, p.mg_hw, p.sh_hw), r_ = mc - b_ * HoWo;
-        const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
-        ooff[pt] = ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + cb) * 2;
-      }
+      for (int pt = 0; pt < MT; ++pt) ooff[pt] = out_off(pt, ok[pt]);   // clamped: loads below are always legal
       // all residual loads first (one latency, not one per pixel tile), then compute + store
       u32x4 rv[RES ? MT : 1][2];
-      if constexpr (RES) {
+      if constexpr (RES && !ROWS) {
         if (!res_pre) {
 #pragma unroll
           for (int pt = 0; pt < MT; ++pt) {
@@ -294,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
-        if constexpr (RES) {
+        if constexpr (RES && !ROWS) {
           if (!res_pre) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -305,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
               }
           }
         }
-        if (ok[pt]) {
+        if (ok[pt] && !(dbg & 32)) {
           char* op = (char*)p.out + ooff[pt];
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
@@ -320,6 +368,16 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
+        if constexpr (RES && ROWS) {              // next tile's residual (prefetched at double step 6) rides in the accumulators
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = ct * 4 + q;
+              const unsigned w_ = rq[pt][i >> 3][(i & 7) >> 1];
+              acc[pt][ct][q] += (i & 1) ? unpack_hi<T>(w_) : unpack_lo<T>(w_);
+            }
+        }
       }
     }
     if (!has_next) break;
@@ -328,10 +386,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     m0 = n_m0; mend = n_mend; R0 = n_R0; patch_src = n_patch_src;
     has_next = tile + G < p.total_tiles;
     if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
-    LANE_SETUP();
+    if constexpr (!ROWS) LANE_SETUP();          // ROWS: every tile has the first tile's address table
     dn -= ND;
     hc = 0;
-    if (full_tile && !res_pre) {
+    if (full_tile && (!res_pre || ROWS)) {
       after_epi = true;                        // the epilogue issued exactly EPI_OPS VM ops per lane
     } else {
       WAIT_VM(0);                              // partial / first residual tile: op count differs -> drain once, static counts stay valid
@@ -348,6 +406,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #undef LOADF
 #undef MFMAS
 #undef TILE_GEOM
+#undef XO
 #undef LANE_SETUP
 }
 
@@ -355,9 +414,14 @@ template <typename T>
 static hipError_t stag_attr() {
   hipError_t e = hipSuccess;
 #define A(PT_, BN_) \
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A(2, 128) A(4, 128) A(6, 128) A(8, 128) A(2, 64) A(4, 64) A(6, 64) A(8, 64)
+#undef A
+#define A(PT_) \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A(4) A(6) A(8)
 #undef A
   return e;
 }
@@ -372,10 +436,19 @@ template <typename T, int BN, bool RES>
 static void stag_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
   const dim3 grid(grid_blocks), block(512);
   switch (pt) {
-    case 2: hipLaunchKernelGGL((conv_stag_kernel<T, 2, BN, RES>), grid, block, lds, st, p); break;
-    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, BN, RES>), grid, block, lds, st, p); break;
-    case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, BN, RES>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, BN, RES>), grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL((conv_stag_kernel<T, 2, BN, RES, false>), grid, block, lds, st, p); break;
+    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, BN, RES, false>), grid, block, lds, st, p); break;
+    case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, BN, RES, false>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, BN, RES, false>), grid, block, lds, st, p); break;
+  }
+}
+template <typename T, bool RES>
+static void stag_rows_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
+  const dim3 grid(grid_blocks), block(512);
+  switch (pt) {
+    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, 64, RES, true>), grid, block, lds, st, p); break;
+    case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, 64, RES, true>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, 64, RES, true>), grid, block, lds, st, p); break;
   }
 }
 
@@ -386,7 +459,11 @@ extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks
   hipStream_t st = (hipStream_t)stream;
   const int pt = p->patch_rows_max;
 #define GO(T, BN_) (p->res ? stag_launch<T, BN_, true>(*p, pt, grid_blocks, lds, st) : stag_launch<T, BN_, false>(*p, pt, grid_blocks, lds, st))
-  if (p->Cout == 64) { if (dtype == 0) GO(bf16_t, 64); else GO(f16_t, 64); }
+  if (p->per_image == 2) {          // ROWS geometry: 8-row bands of one image (p->tiles_per_image bands per image)
+    if (p->Cout != 64 || p->Wo > 64 || p->Ho % 8 || pt < 4) return (int)hipErrorInvalidValue;
+    if (dtype == 0) { if (p->res) stag_rows_launch<bf16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<bf16_t, false>(*p, pt, grid_blocks, lds, st); }
+    else            { if (p->res) stag_rows_launch<f16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<f16_t, false>(*p, pt, grid_blocks, lds, st); }
+  } else if (p->Cout == 64) { if (dtype == 0) GO(bf16_t, 64); else GO(f16_t, 64); }
   else               { if (dtype == 0) GO(bf16_t, 128); else GO(f16_t, 128); }
 #undef GO
   return (int)hipGetLastError();

@@ -82,7 +82,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 1;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
@@ -203,6 +203,14 @@ void plan_conv(flope_engine* e, Conv& c) {
     if (P < 2) P = 2;
     const size_t lds = (size_t)6 * sbn * 64 + (size_t)2 * P * 8192;   // 3 double tiles + 2 patch buffers
     if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }
+    // layer-1 shape: 8-row bands of one image per tile (constant tile geometry, 7 bands per 56-row image)
+    if (c.cout == 64 && e->opt_stag >= 3 && c.hout % 8 == 0 && c.wout <= 64) {
+      int Pr = (int)(((long)10 * Wip * 4 + 511) / 512);
+      Pr = (Pr + 1) & ~1;
+      if (Pr < 4) Pr = 4;
+      const size_t ldsr = (size_t)6 * sbn * 64 + (size_t)2 * Pr * 8192;
+      if (Pr <= 8 && ldsr <= kLdsMax) { c.stag = 2; c.stag_patch_bytes = Pr; c.stag_lds = ldsr; }
+    }
   }
 }
 
@@ -425,7 +433,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
-  else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 2 ? 2 : value); }
+  else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
   else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
   else if (!strcmp(name, "fuse_stem")) { prev = e->opt_fuse_stem; e->opt_fuse_stem = value != 0; return prev; }
   else if (!strcmp(name, "ldspad")) { prev = e->opt_ldspad; e->opt_ldspad = value; return prev; }
@@ -545,8 +553,11 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       const int sbm = c.cout == 64 ? 512 : 256;
       p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + sbm - 1) / sbm; p.ntiles = c.cout == 64 ? 1 : c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
       p.total_tiles = p.mtiles * p.ntiles;
-      // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile)
+      if (c.stag == 2) { p.per_image = 2; p.tiles_per_image = c.hout / 8; p.mtiles = batch * p.tiles_per_image; p.total_tiles = p.mtiles; }
+      // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile); the
+      // row-band kernel is always persistent and shares the CUs with the other batch slices in flight
       int gridb = e->opt_persist ? std::min(p.total_tiles, e->num_cus) : p.total_tiles;
+      if (c.stag == 2) gridb = std::min(p.total_tiles, std::max(1, e->num_cus / std::max(1, e->cur_slices)));
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
       SMARK();
@@ -580,6 +591,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   e->last_batch = batch;
   int ns = (e->opt_streams >= 2 && !e->opt_profile) ? e->opt_streams : 1;
   while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
+  e->cur_slices = ns;
   if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true);
   hipStream_t user = (hipStream_t)stream;
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
@@ -681,7 +693,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     int BM, BN; tile_dims(c.cfg, &BM, &BN);
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
-    else if (c.stag) snprintf(k, sizeof k, c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>");
+    else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
@@ -701,7 +713,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
   snprintf(line, sizeof line, "stem: tiles/img=%d rows=%d lds=%zu\n", e->stem_tiles, e->stem_rows, e->stem_lds);
   s += line;
   for (const Conv& c : e->convs) {
-    if (c.stag) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
+    if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);
     s += line;

@@ -77,6 +77,25 @@ def test_mfma_path_every_stage_vs_emulating_oracle(state_dict, dtype, opts, H, W
     e.close()
 
 
+@pytest.mark.parametrize("H,W,B,streams", [(224, 224, 40, 1), (224, 224, 70, 2), (96, 80, 3, 1), (64, 256, 2, 1)])
+def test_layer1_row_band_kernel_every_stage(state_dict, H, W, B, streams):
+    """stag=3 (default): layer 1 as persistent 8-row bands.  B = 40 x 7 bands = 280 tiles on <= 256 workgroups, so some
+    workgroups walk two tiles (next-tile patch + residual prefetch); 64x256 has a 64-wide layer 1 (no padded columns);
+    96x80 a 20-wide one (44 padded columns per row)."""
+    torch.manual_seed(13)
+    x = torch.rand(B, 3, H, W)
+    emu = O.forward_stages_emulated(state_dict, x, torch.float16)
+    e = _engine(state_dict, H, W, B, "f16", stag=3, streams=streams)
+    assert "8-row bands" in e.describe_plan()
+    r9, _ = _run(e, x)
+    for s in STAGES:
+        if s == "stem":
+            continue
+        assert _rel(e.read_stage(s, B).cpu(), emu[s]) <= 2e-3, s
+    assert _rel(r9, emu["r9"]) <= 2e-3
+    e.close()
+
+
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
 def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg):
     """BASELINE cfg1 inputs (16 seeded 224x224 crops) against the committed goldens."""

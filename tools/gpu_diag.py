@@ -75,6 +75,15 @@ def main():
     quick = "--quick" in sys.argv
     print(torch.cuda.get_device_name(0), flush=True)
     sd = synthetic_state_dict(0)
+    if "--rows" in sys.argv:           # the row-band layer-1 kernel (stag=3) only
+        e = PoseEngine(224, 224, 256, "f16"); e.set_option("stag", 3); print(e.describe_plan()); e.close()
+        for hw in ((224, 224, 48), (224, 224, 5), (96, 80, 3), (65, 71, 2), (64, 256, 3)):
+            for st in (1, 2):
+                safe(parity, sd, hw[0], hw[1], hw[2], "f16", dict(fuse_stem=1, stag=3, streams=st))
+        safe(parity, sd, 224, 224, 7, "bf16", dict(fuse_stem=1, stag=3))
+        for opts in [dict(streams=2, stag=1), dict(streams=2, stag=3), dict(streams=1, stag=3), dict(streams=1, stag=1)]:
+            safe(timing, sd, 224, 224, 256, "f16", opts)
+        return
     e = PoseEngine(224, 224, 256, "f16"); print(e.describe_plan()); e.close()
     safe(parity, sd, 96, 80, 3, "f32", {})
     safe(parity, sd, 224, 224, 48, "f16", dict(fuse_stem=1, stag=2, persist=1))
