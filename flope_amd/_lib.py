@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflope_amd.so")
+LIB_PATH = os.environ.get("FLOPE_AMD_LIB") or os.path.join(_HERE, "lib", "libflope_amd.so")   # override: A/B builds only
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 IN_F32_NCHW, IN_BF16_NHWC, IN_F16_NHWC, IN_U8_NHWC = 0, 1, 2, 3

@@ -53,6 +53,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   constexpr int TG = DT_B / 8192;                           // LDS-DMA ops per wave per double tile (2 / 1)
   constexpr int MT = 4, NT = 4;
   constexpr int PATCH_B = PT * 8192;                              // bytes of one patch buffer
+  // WRES (ROWS with an odd PT): the whole 18 x 4 KB weight panel of a 64 -> 64 layer stays in LDS for the life of the
+  // workgroup instead of being re-streamed per tile -- the chip-wide L2 -> LDS DMA rate (~6.5-8.7 TB/s measured) is the
+  // floor under these kernels, and at K = 576 the weight ring was half of this layer's DMA bytes.
+  constexpr bool WRES = ROWS && (PT & 1);
   constexpr int EPI_OPS = MT * 2 + ((RES && !ROWS) ? MT * 2 : 0);  // 16-byte stores (+ residual loads, unless prefetched: ROWS) per lane per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;                                   // 2 patch buffers (first: their offsets stay ds_read immediates)
@@ -164,11 +168,11 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
 
   // fragment reads of one double step: ring slot, patch buffers and taps are literals
-#define LOADF(slot_, buf0_, tap0_, buf1_, tap1_)                                                               \
+#define LOADF(slot_, buf0_, tap0_, buf1_, tap1_)   /* slot_: byte offset of the double tile's first row for this lane */                                                               \
   do {                                                                                                         \
     _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) {                                                        \
-      wf[0][ct] = *(const frag*)(smem + wbase + (slot_) * DT_B + ct * 1024);                                   \
-      wf[1][ct] = *(const frag*)(smem + wbase + (slot_) * DT_B + TILE_B + ct * 1024);                          \
+      wf[0][ct] = *(const frag*)(smem + (slot_) + ct * 1024);                                                  \
+      wf[1][ct] = *(const frag*)(smem + (slot_) + TILE_B + ct * 1024);                                         \
     }                                                                                                          \
     _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
       xf[0][pt] = *(const frag*)(smem + XO(tap0_, pt) + (buf0_) * PATCH_B);                                    \
@@ -233,9 +237,15 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   }
   // ---- prologue: patch of half-chunk 0, double tiles 0 and 1
   ISSUE_PATCH(patch_src, 0);
-  ISSUE_DT(0, 0);
-  ISSUE_DT(1, 1);
-  WAIT_VM(TG);                                 // patch 0 and double tile 0 landed (double tile 1 may fly)
+  if constexpr (WRES) {
+    const char* wsrc = (const char*)p.w + (size_t)ntile * NS * TILE_B + lane16;
+    for (int i = wave; i < 18 * TILE_B / 1024; i += 8) GLDS16(wsrc + i * 1024, Bs + i * 1024);
+    WAIT_VM(0);                                // patch 0 and the resident weight panel landed (once per workgroup)
+  } else {
+    ISSUE_DT(0, 0);
+    ISSUE_DT(1, 1);
+    WAIT_VM(TG);                               // patch 0 and double tile 0 landed (double tile 1 may fly)
+  }
   if constexpr (RES) {
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt)
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     constexpr int U0_ = 2 * (D), U1_ = 2 * (D) + 1;                                                            \
     constexpr int WN_ = TG + (((D) == 0 || (D) == 1 || (D) == 5 || (D) == 6) ? PT : 0) +                       \
                         ((RES && ROWS && ((D) == 6 || (D) == 7)) ? 2 * MT : 0);                                \
-    if (!(dbg & 1)) {                                                                                          \
+    if (!WRES && !(dbg & 1)) {                                                                                 \
       const int di_ = dn < ND ? dn : dn - ND;                                                                  \
       ISSUE_DT(di_, ((D) + 2) % NBD);                                                                          \
     }                                                                                                          \
@@ -301,8 +311,16 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         rq[pt][1] = *(const u32x4*)(rp_ + 16);                                                                 \
       }                                                                                                        \
     }                                                                                                          \
-    if (!(dbg & 16)) LOADF((D) % NBD, U0_ / 9, U0_ % 9, U1_ / 9, U1_ % 9);                                     \
-    if (dbg & 3) WAIT_VM(0);                                                                                   \
+    /* ring: slot offsets fold into the ds_read immediates.  WRES: 72 KB of distinct offsets do not fit 16-bit     \
+       immediates and the compiler would hoist one base register per step out of the tile loop (+48 VGPRs):       \
+       one opaque add per step instead */                                                                      \
+    int wof_ = wbase + (WRES ? (D) : (D) % NBD) * DT_B;                                                        \
+    if constexpr (WRES) { wof_ = wbase; asm volatile("" : "+v"(wof_)); wof_ += (D) * DT_B; }                   \
+    if (!(dbg & 16)) LOADF(wof_, U0_ / 9, U0_ % 9, U1_ / 9, U1_ % 9);                                          \
+    if constexpr (WRES) {      /* only the patch bursts of steps 0 / 5 are in flight: landed before steps 4 / 9 */ \
+      if ((D) == 3) WAIT_VM(0);                                                                                \
+      if ((D) == 8) WAIT_VM(RES ? 2 * MT : 0);     /* the residual prefetch of step 6 is younger */            \
+    } else if (dbg & 3) WAIT_VM(0);                                                                            \
     else if ((D) == 0 && after_epi) WAIT_VM(WN_ + EPI_OPS);                                                    \
     else WAIT_VM(WN_);                                                                                         \
     BARRIER();                                                                                                 \
@@ -421,7 +439,7 @@ static hipError_t stag_attr() {
 #define A(PT_) \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A(4) A(6) A(8)
+  A(3) A(5) A(6) A(8)
 #undef A
   return e;
 }
@@ -446,7 +464,8 @@ template <typename T, bool RES>
 static void stag_rows_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
   const dim3 grid(grid_blocks), block(512);
   switch (pt) {
-    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, 64, RES, true>), grid, block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL((conv_stag_kernel<T, 3, 64, RES, true>), grid, block, lds, st, p); break;   // odd: weights resident
+    case 5: hipLaunchKernelGGL((conv_stag_kernel<T, 5, 64, RES, true>), grid, block, lds, st, p); break;
     case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, 64, RES, true>), grid, block, lds, st, p); break;
     default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, 64, RES, true>), grid, block, lds, st, p); break;
   }
@@ -460,7 +479,7 @@ extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks
   const int pt = p->patch_rows_max;
 #define GO(T, BN_) (p->res ? stag_launch<T, BN_, true>(*p, pt, grid_blocks, lds, st) : stag_launch<T, BN_, false>(*p, pt, grid_blocks, lds, st))
   if (p->per_image == 2) {          // ROWS geometry: 8-row bands of one image (p->tiles_per_image bands per image)
-    if (p->Cout != 64 || p->Wo > 64 || p->Ho % 8 || pt < 4) return (int)hipErrorInvalidValue;
+    if (p->Cout != 64 || p->Wo > 64 || p->Ho % 8 || (pt != 3 && pt != 5 && pt != 6 && pt != 8) || ((pt & 1) && p->Cin != 64)) return (int)hipErrorInvalidValue;
     if (dtype == 0) { if (p->res) stag_rows_launch<bf16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<bf16_t, false>(*p, pt, grid_blocks, lds, st); }
     else            { if (p->res) stag_rows_launch<f16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<f16_t, false>(*p, pt, grid_blocks, lds, st); }
   } else if (p->Cout == 64) { if (dtype == 0) GO(bf16_t, 64); else GO(f16_t, 64); }

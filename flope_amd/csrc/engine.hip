@@ -206,9 +206,9 @@ void plan_conv(flope_engine* e, Conv& c) {
     // layer-1 shape: 8-row bands of one image per tile (constant tile geometry, 7 bands per 56-row image)
     if (c.cout == 64 && e->opt_stag >= 3 && c.hout % 8 == 0 && c.wout <= 64) {
       int Pr = (int)(((long)10 * Wip * 4 + 511) / 512);
-      Pr = (Pr + 1) & ~1;
-      if (Pr < 4) Pr = 4;
-      const size_t ldsr = (size_t)6 * sbn * 64 + (size_t)2 * Pr * 8192;
+      // odd Pr (3, 5) = the instantiations that keep the 72 KB weight panel of a 64 -> 64 layer resident in LDS
+      if (c.cin == 64 && Pr <= 5) Pr = Pr <= 3 ? 3 : 5; else Pr = Pr <= 6 ? 6 : 8;
+      const size_t ldsr = ((Pr & 1) ? (size_t)18 * 4096 : (size_t)6 * sbn * 64) + (size_t)2 * Pr * 8192;
       if (Pr <= 8 && ldsr <= kLdsMax) { c.stag = 2; c.stag_patch_bytes = Pr; c.stag_lds = ldsr; }
     }
   }
