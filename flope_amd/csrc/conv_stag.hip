@@ -434,7 +434,7 @@ static hipError_t stag_attr() {
 #define A(PT_, BN_) \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, BN_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A(2, 128) A(4, 128) A(6, 128) A(8, 128) A(2, 64) A(4, 64) A(6, 64) A(8, 64)
+  A(2, 128) A(3, 128) A(4, 128) A(5, 128) A(6, 128) A(8, 128) A(2, 64) A(3, 64) A(4, 64) A(5, 64) A(6, 64) A(8, 64)
 #undef A
 #define A(PT_) \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -455,7 +455,9 @@ static void stag_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hip
   const dim3 grid(grid_blocks), block(512);
   switch (pt) {
     case 2: hipLaunchKernelGGL((conv_stag_kernel<T, 2, BN, RES, false>), grid, block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL((conv_stag_kernel<T, 3, BN, RES, false>), grid, block, lds, st, p); break;
     case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, BN, RES, false>), grid, block, lds, st, p); break;
+    case 5: hipLaunchKernelGGL((conv_stag_kernel<T, 5, BN, RES, false>), grid, block, lds, st, p); break;
     case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, BN, RES, false>), grid, block, lds, st, p); break;
     default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, BN, RES, false>), grid, block, lds, st, p); break;
   }
@@ -471,7 +473,7 @@ static void stag_rows_launch(const ConvP& p, int pt, int grid_blocks, size_t lds
   }
 }
 
-// p->patch_rows_max carries PT (2, 4, 6 or 8 DMA rounds per patch buffer); Cout == 64 selects the 512 x 64 tile;
+// p->patch_rows_max carries PT (2..6 or 8 DMA rounds per patch buffer); Cout == 64 selects the 512 x 64 tile;
 // p->total_tiles = mtiles * ntiles; grid_blocks <= total_tiles and a multiple of ntiles;
 // lds = 2*PT*8 KiB + 3 * 2 * (BN*64 B)
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream) {
