@@ -80,7 +80,12 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
       off[k] = (yc * p.W + xc) * estep;
     }
     const size_t img_elems = (size_t)3 * p.H * p.W;
+#if defined(FLOPE_STEM_ABL) && (FLOPE_STEM_ABL & 1)      // timing experiments only
+    for (int k = 0; k < NI; ++k) { v0[k] = v1[k] = v2[k] = 0.5f; }
+    if (false) {
+#else
     if (p.in_format == 0) {
+#endif
       const float* s = (const float*)p.x + (size_t)img * img_elems;
       const int plane = p.H * p.W;
 #pragma unroll
@@ -146,8 +151,12 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
   }
+#if defined(FLOPE_STEM_ABL) && (FLOPE_STEM_ABL & 2)
+  for (int ky = 0; ky < 0; ++ky) {
+#else
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky) {
+#endif
     frag wf[NT], xf[MT];
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(Ws + ky * 4096 + ct * 1024 + wo_);
@@ -207,6 +216,9 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
         for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
       }
     char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
+#if defined(FLOPE_STEM_ABL) && (FLOPE_STEM_ABL & 4)
+    if (o[0] == 0x12345678u)
+#endif
     *(u32x4*)dst = o;
   }
 }
