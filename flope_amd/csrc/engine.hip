@@ -82,7 +82,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
@@ -433,6 +433,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
+  else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
+  else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
   else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
   else if (!strcmp(name, "fuse_stem")) { prev = e->opt_fuse_stem; e->opt_fuse_stem = value != 0; return prev; }
@@ -557,7 +559,9 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile); the
       // row-band kernel is always persistent and shares the CUs with the other batch slices in flight
       int gridb = e->opt_persist ? std::min(p.total_tiles, e->num_cus) : p.total_tiles;
-      if (c.stag == 2) gridb = std::min(p.total_tiles, std::max(1, e->num_cus / std::max(1, e->cur_slices)));
+      if (c.stag == 2)    // this slice's share of the CUs (slices in flight together cover the chip once)
+        gridb = std::min(p.total_tiles, e->opt_rows_grid > 0 ? e->opt_rows_grid
+                                          : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
       SMARK();
@@ -592,6 +596,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   int ns = (e->opt_streams >= 2 && !e->opt_profile) ? e->opt_streams : 1;
   while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
   e->cur_slices = ns;
+  e->cur_batch = batch;
   if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true);
   hipStream_t user = (hipStream_t)stream;
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
@@ -599,7 +604,16 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   // hardware queues interleave them, and a slice's short tail round overlaps another slice's next launch.
   for (int s = 0; s < ns; ++s) {
     HIP_TRY(e, hipStreamWaitEvent(e->side[s], e->ev_fork, 0));
-    const int start = (int)((long)batch * s / ns), cnt = (int)((long)batch * (s + 1) / ns) - start;
+    int start = (int)((long)batch * s / ns), cnt = (int)((long)batch * (s + 1) / ns) - start;
+    if (ns == 2) {
+      // Two slices of 3/8 and 5/8 of the batch (multiples of 8 images, so every layer's tiles stay whole) instead of
+      // two halves: equal halves run the same layer at the same time and compete for the same resource; the uneven
+      // pair stays out of phase (B = 256: 96/160 1.199 ms vs 128/128 1.215 ms, same-run A/B; "split" overrides).
+      int first = e->opt_split > 100 ? e->opt_split - 100 : (int)((long)batch * e->opt_split / 100);
+      if (e->opt_split == 0) first = batch >= 128 ? (batch * 3 / 8) & ~7 : batch / 2;
+      first = std::max(1, std::min(batch - 1, first));
+      start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
+    }
     int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(e->ev_join[s], e->side[s]));
