@@ -604,7 +604,9 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   // hardware queues interleave them, and a slice's short tail round overlaps another slice's next launch.
   for (int s = 0; s < ns; ++s) {
     HIP_TRY(e, hipStreamWaitEvent(e->side[s], e->ev_fork, 0));
-    int start = (int)((long)batch * s / ns), cnt = (int)((long)batch * (s + 1) / ns) - start;
+    // slice boundaries on multiples of 8 images (whole tiles in every layer) when the batch allows it
+    auto bound = [&](int k) { const int b_ = (int)((long)batch * k / ns); return (batch >= 16 * ns && k > 0 && k < ns) ? ((b_ + 4) & ~7) : b_; };
+    int start = bound(s), cnt = bound(s + 1) - start;
     if (ns == 2) {
       // Two slices of 3/8 and 5/8 of the batch (multiples of 8 images, so every layer's tiles stay whole) instead of
       // two halves: equal halves run the same layer at the same time and compete for the same resource; the uneven
