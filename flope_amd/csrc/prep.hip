@@ -296,3 +296,56 @@ extern "C" int flope_depth_lift(const void* depth_dev, int depth_format, const u
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- get_bbox_mask post-processing (reference fast_pose_predictor.py:50-54) ------------------------------------
+// sum over instance masks -> clip [0,1] -> x255 -> uint8 (numpy astype truncation) at the detector's resolution
+__global__ void merge_masks_kernel(const float* masks, int n, int hw, uint8_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += masks[(size_t)k * hw + i];
+  s = fminf(fmaxf(s, 0.f), 1.f) * 255.f;
+  out[i] = (uint8_t)s;
+}
+
+// One axis of cv2's INTER_LINEAR tables for 8-bit images (resize.cpp): source index, 11-bit fixed-point weights.
+// The fraction is formed exactly as OpenCV does -- double product, float cast, float subtract -- with explicit
+// round-to-nearest intrinsics so that no fused multiply-add changes a bit.
+__device__ __forceinline__ void linear_tap(int d, int src, double scale, int* s0, int* s1, int* a0, int* a1) {
+  const float f = (float)__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5);
+  int s = (int)floorf(f);
+  float fr = __fsub_rn(f, (float)s);
+  if (s < 0) { fr = 0.f; s = 0; }
+  if (s >= src - 1) { fr = 0.f; s = src - 1; }
+  *a1 = (int)rintf(__fmul_rn(fr, 2048.f));
+  *a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fr), 2048.f));
+  *s0 = s;
+  *s1 = min(s + 1, src - 1);
+}
+
+__global__ void resize_linear_u8_kernel(const uint8_t* in, int h, int w, uint8_t* out, int H, int W, double sx,
+                                        double sy) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  int x0, x1, a0, a1, y0, y1, b0, b1;
+  linear_tap(x, w, sx, &x0, &x1, &a0, &a1);
+  linear_tap(y, h, sy, &y0, &y1, &b0, &b1);
+  const int S0 = in[(size_t)y0 * w + x0] * a0 + in[(size_t)y0 * w + x1] * a1;
+  const int S1 = in[(size_t)y1 * w + x0] * a0 + in[(size_t)y1 * w + x1] * a1;
+  out[(size_t)y * W + x] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+
+extern "C" int flope_merge_masks_resize(const float* masks_dev, int n, int h, int w, uint8_t* scratch_dev,
+                                        uint8_t* out_dev, int H, int W, void* stream) {
+  if (n < 0 || h < 1 || w < 1 || H < 1 || W < 1 || !out_dev || (n > 0 && !masks_dev)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return hipMemsetAsync(out_dev, 0, (size_t)H * W, st) == hipSuccess ? 0 : -2;
+  const bool same = h == H && w == W;                      // cv2.resize copies when the size does not change
+  if (!same && !scratch_dev) return -1;
+  uint8_t* merged = same ? out_dev : scratch_dev;
+  hipLaunchKernelGGL(merge_masks_kernel, dim3((h * w + 255) / 256), dim3(256), 0, st, masks_dev, n, h * w, merged);
+  if (!same)
+    hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, merged, h, w, out_dev, H, W,
+                       (double)w / W, (double)h / H);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

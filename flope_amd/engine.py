@@ -237,6 +237,23 @@ def crop_resize_mask(frame: torch.Tensor, mask: torch.Tensor, boxes: torch.Tenso
     return out
 
 
+def merge_masks_resize(masks: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Instance masks float32 [n,h,w] on the GPU -> uint8 [H,W] frame mask (fast_pose_predictor.py:50-54:
+    sum, clip to [0,1], x255, uint8, cv2.resize default bilinear), all on the device."""
+    _require_gpu()
+    if masks.dim() != 3:
+        raise ValueError(f"expected masks [n,h,w], got {tuple(masks.shape)}")
+    if not masks.is_cuda:
+        raise RuntimeError("masks must live on the GPU; no CPU path")
+    m = masks.to(torch.float32).contiguous()
+    n, h, w = m.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=m.device)
+    scratch = torch.empty(h * w, dtype=torch.uint8, device=m.device)
+    _lib.check(_lib.load().flope_merge_masks_resize(m.data_ptr() if n else None, n, h, w, scratch.data_ptr(), out.data_ptr(),
+                                                    H, W, _stream_ptr(m.device)))
+    return out
+
+
 def depth_lift(depth_raw: torch.Tensor, mask: torch.Tensor, boxes: torch.Tensor, K4, depth_div: float,
                near: float, far: float):
     """depth uint16 (raw) or float32 [H,W], mask uint8 [H,W], boxes int32 [N,4]; metres = depth / depth_div

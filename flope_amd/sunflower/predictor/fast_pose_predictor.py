@@ -92,11 +92,8 @@ class FastPosePredictor:
         """fast_pose_predictor.py:44-57 on top of ultralytics (third-party, parity unpinned)."""
         H, W, _ = image.shape
         res = self.yolo(image)[0]
-        m = (torch.clip(res.masks.data.sum(dim=0), 0, 1) * 255).to(torch.uint8)
-        # cv2.resize default (bilinear, half-pixel centres) to the frame size
-        m = torch.nn.functional.interpolate(m[None, None].float(), size=(H, W), mode="bilinear",
-                                            align_corners=False)[0, 0]
-        return res.boxes.xyxy.cpu().numpy().astype(np.int16), m.round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        mask = _engine.merge_masks_resize(res.masks.data.to(self.device), H, W)      # sum/clip/x255/uint8/cv2.resize on the GPU
+        return res.boxes.xyxy.cpu().numpy().astype(np.int16), mask.cpu().numpy()
 
     def get_bbox_mask(self, image):
         """-> (bbox int16 [N,4] xyxy, mask uint8 [H,W])"""

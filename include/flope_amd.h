@@ -113,6 +113,13 @@ int flope_crop_resize_mask(const uint8_t* frame_dev, const uint8_t* mask_dev,
                            int frame_h, int frame_w, const int32_t* boxes_dev, int n,
                            int size, int out_format, void* out_dev, void* stream);
 
+/* Detector post-processing of `get_bbox_mask` (fast_pose_predictor.py:50-54): sum of the n
+ * instance masks (float32 [n,h,w], any values) -> clip to [0,1] -> x255 -> uint8 -> bilinear
+ * resize to the frame (cv2.resize default INTER_LINEAR, 8-bit fixed-point arithmetic) ->
+ * out_dev uint8 [H,W].  n == 0 gives an all-zero mask.  scratch_dev: >= h*w bytes. */
+int flope_merge_masks_resize(const float* masks_dev, int n, int h, int w, uint8_t* scratch_dev,
+                             uint8_t* out_dev, int H, int W, void* stream);
+
 /* Depth statistics + back-projection (image_manipulation.py:39-96, mvg.py:387-408):
  * valid = (near < d < far) & (mask > 128), eroded by the 10x10 ellipse; per box the
  * mean of valid depths, count >= 50 => reliable; xyz = K^-1 [u,v,1]^T * d/|K^-1[u,v,1]|.

@@ -158,6 +158,49 @@ def resize_lanczos4_u8(img, size):
     return out[:, :, 0] if squeeze else out
 
 
+def _linear_axis_table(src: int, dst: int):
+    """cv2 resize.cpp, INTER_LINEAR coefficient tables for one axis of an 8-bit image: fixed point, 11 bits
+    (INTER_RESIZE_COEF_BITS), float32 fraction exactly as `fx = (float)((dx+0.5)*scale - 0.5); sx = cvFloor(fx); fx -= sx`."""
+    scale = src / dst                                           # double
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s0 = np.floor(f).astype(np.int64)
+    fr = (f - s0.astype(np.float32)).astype(np.float32)
+    lo = s0 < 0
+    fr[lo] = 0; s0[lo] = 0
+    hi = s0 >= src - 1
+    fr[hi] = 0; s0[hi] = src - 1
+    a1 = np.rint(fr * np.float32(2048)).astype(np.int64)        # saturate_cast<short>(float) = round half to even
+    a0 = np.rint((np.float32(1) - fr) * np.float32(2048)).astype(np.int64)
+    s1 = np.minimum(s0 + 1, src - 1)                            # weight 0 wherever this clamp bites
+    return s0, s1, a0, a1
+
+
+def resize_linear_u8(img, size_wh):
+    """cv2.resize(img, (W, H)) (default INTER_LINEAR) for a uint8 HxW image (fast_pose_predictor.py:54):
+    horizontal pass in 32-bit ints at scale 2048, vertical pass
+        dst = ((b0 * (S0 >> 4) >> 16) + (b1 * (S1 >> 4) >> 16) + 2) >> 2
+    (resize.cpp VResizeLinear<uchar,int,short,...>).  cv2 is not installed here: restated from the published source,
+    PARITY UNPINNED against cv2 itself.  (cv2 switches an exact 2x downscale to INTER_AREA; not restated.)"""
+    img = np.asarray(img, dtype=np.uint8)
+    h, w = img.shape
+    W, H = size_wh
+    if (h, w) == (H, W):
+        return img.copy()
+    x0, x1, a0, a1 = _linear_axis_table(w, W)
+    y0, y1, b0, b1 = _linear_axis_table(h, H)
+    src = img.astype(np.int64)
+    hor = src[:, x0] * a0 + src[:, x1] * a1                     # [h, W]
+    S0, S1 = hor[y0], hor[y1]
+    out = (((b0[:, None] * (S0 >> 4)) >> 16) + ((b1[:, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def merge_masks(masks, size_wh):
+    """fast_pose_predictor.py:50-54: sum the instance masks, clip to [0,1], x255, uint8, resize to the frame."""
+    m = np.clip(np.asarray(masks, dtype=np.float32).sum(axis=0), 0, 1) * 255
+    return resize_linear_u8(m.astype(np.uint8), size_wh)
+
+
 # ---- image_manipulation.py -----------------------------------------------------------------
 
 def get_depth_value(bbox, depth, seg_mask, scale=None, near_plane=0.1, far_plane=3.0):

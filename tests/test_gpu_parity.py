@@ -209,6 +209,20 @@ def test_crop_resize_mask_vs_oracle():
         assert (diff > 1e-6).mean() < 1e-3                                      # and bit-identical almost everywhere
 
 
+@pytest.mark.parametrize("n,h,w,H,W", [(5, 160, 288, 1080, 1920), (3, 37, 53, 90, 160), (2, 64, 48, 40, 30), (4, 24, 32, 24, 32),
+                                       (0, 16, 16, 20, 28), (1, 7, 5, 480, 640)])
+def test_merge_masks_resize_bit_exact_vs_oracle(n, h, w, H, W):
+    """get_bbox_mask post-processing (fast_pose_predictor.py:50-54) on the device: bit-exact against the restatement of
+    cv2.resize's 8-bit INTER_LINEAR arithmetic (up- and down-scaling, non-integer ratios, unchanged size, no detections)."""
+    from flope_amd import engine as E
+    rng = np.random.default_rng(n * 1000 + h)
+    masks = (rng.random((n, h, w)) < 0.3).astype(np.float32) * rng.choice([1.0, 0.4, 0.7], size=(n, 1, 1)).astype(np.float32)
+    got = E.merge_masks_resize(torch.from_numpy(masks).cuda(), H, W).cpu().numpy()
+    ref = P.merge_masks(masks, (W, H)) if n else np.zeros((H, W), np.uint8)
+    assert got.shape == (H, W) and got.dtype == np.uint8
+    assert np.array_equal(got, ref), int((got != ref).sum())
+
+
 def test_depth_lift_vs_oracle():
     from flope_amd import engine as E
     rgb, mask, depth, boxes = _scene(21)

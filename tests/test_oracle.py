@@ -162,3 +162,33 @@ def test_tf_encoder_oracle_properties():
     assert np.allclose(T.forward(sd, x[:, perm], num_heads=2), y[:, perm], atol=1e-10)
     # sequences of a batch are independent
     assert np.allclose(T.forward(sd, x[1:2], num_heads=2), y[1:2], atol=1e-10)
+
+
+# ---- get_bbox_mask post-processing: cv2.resize default (INTER_LINEAR, 8-bit fixed point) restatement -----------
+def test_resize_linear_u8_kats():
+    # same size: a copy; constant images stay constant (weights sum to 2048)
+    img = (np.arange(48, dtype=np.uint8) * 5).reshape(6, 8)
+    assert np.array_equal(P.resize_linear_u8(img, (8, 6)), img)
+    assert np.array_equal(P.resize_linear_u8(np.full((7, 9), 201, np.uint8), (31, 23)), np.full((23, 31), 201, np.uint8))
+    # 1 x 2 -> 1 x 4 by hand: centres at -0.25, 0.25, 0.75, 1.25 -> weights (clamped) 0, .25, .75, 1 of the right pixel
+    out = P.resize_linear_u8(np.array([[0, 200]], np.uint8), (4, 1))
+    assert out.tolist() == [[0, 50, 150, 200]]
+    # the fixed-point vertical pass: 2 x 1 -> 4 x 1 gives the same profile
+    assert P.resize_linear_u8(np.array([[0], [200]], np.uint8), (1, 4)).ravel().tolist() == [0, 50, 150, 200]
+    # against a float bilinear reference the 11-bit arithmetic is within one grey level
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    W, H = 160, 90
+    fx = np.clip((np.arange(W) + 0.5) * 53 / W - 0.5, 0, 52); fy = np.clip((np.arange(H) + 0.5) * 37 / H - 0.5, 0, 36)
+    x0 = np.minimum(np.floor(fx).astype(int), 51); y0 = np.minimum(np.floor(fy).astype(int), 35)
+    ax = (fx - x0)[None, :]; ay = (fy - y0)[:, None]
+    s = src.astype(np.float64)
+    ref = (s[y0][:, x0] * (1 - ax) + s[y0][:, x0 + 1] * ax) * (1 - ay) + (s[y0 + 1][:, x0] * (1 - ax) + s[y0 + 1][:, x0 + 1] * ax) * ay
+    assert np.abs(P.resize_linear_u8(src, (W, H)).astype(np.float64) - ref).max() <= 1.0
+
+
+def test_merge_masks_kat():
+    m = np.zeros((3, 4, 4), np.float32)
+    m[0, :2] = 1; m[1, 1:3] = 1; m[2, 3, 3] = 0.5          # overlaps clip to 1; 0.5 -> 127 (numpy astype truncates)
+    out = P.merge_masks(m, (4, 4))
+    assert out[:3].tolist() == [[255] * 4] * 3 and out[3].tolist() == [0, 0, 0, 127]
