@@ -114,6 +114,7 @@ def main():
         xyz = torch.zeros(B, 3, device=dev)                      # translation comes from depth (cfg3); zeros here
         poses = torch.empty(max(K, 1), B, 16, device=dev)
         run_steps(eng, x, fmt, W, poses, R, xyz)
+        D.gather_poses(poses.view(K * B, 16))                    # untimed: RCCL communicator / channel set-up for this collective
         D.barrier(); torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         run_steps(eng, x, fmt, K, poses, R, xyz)
