@@ -83,7 +83,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no HIP device visible (the product path has no CPU fallback)")
-    rank, world, local = D.init_from_env("nccl")
+    # FLOPE_BENCH_REHEARSE=1: rehearse the N > 1 control flow on a box with ONE GPU (every rank on cuda:0, gloo instead
+    # of RCCL, poses gathered through host memory).  Never used for reported numbers.
+    rehearse = os.environ.get("FLOPE_BENCH_REHEARSE") == "1"
+    rank, world, local = D.init_from_env("gloo" if rehearse else "nccl")
+    if rehearse:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -114,13 +119,13 @@ def main():
         xyz = torch.zeros(B, 3, device=dev)                      # translation comes from depth (cfg3); zeros here
         poses = torch.empty(max(K, 1), B, 16, device=dev)
         run_steps(eng, x, fmt, W, poses, R, xyz)
-        D.gather_poses(poses.view(K * B, 16))                    # untimed: RCCL communicator / channel set-up for this collective
+        D.gather_poses(poses.view(K * B, 16).cpu() if rehearse else poses.view(K * B, 16))   # untimed: RCCL communicator / channel set-up
         D.barrier(); torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         run_steps(eng, x, fmt, K, poses, R, xyz)
-        allp = D.gather_poses(poses.view(K * B, 16))
+        allp = D.gather_poses(poses.view(K * B, 16).cpu() if rehearse else poses.view(K * B, 16))
         D.barrier(); torch.cuda.synchronize(dev)
-        dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+        dt = D.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearse else dev)
         assert allp.shape == (world * K * B, 16)
         return eng, x, fmt, dt, R, xyz, poses
 
@@ -130,7 +135,7 @@ def main():
     out = {
         "metric": "poses_per_sec", "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearse else ""),
         "config": {"workload": f"PoseResNet (ResNet-18 trunk + fp32 head) forward + special Procrustes + pose assembly, "
                                f"batch {B} x {S}x{S}x3 16-bit NHWC crops resident in HBM per GPU (BASELINE configs[1]); "
                                f"one RCCL all-gather of the poses per run when N>1 (configs[3])",
