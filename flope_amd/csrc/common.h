@@ -127,13 +127,8 @@ struct NaiveConvP {    // strict fp32 direct convolution on padded NHWC float te
 // acc + bias (+ residual) (ReLU) -> 16-bit, written as 16-byte NHWC stores into the
 // interior of the zero-bordered output tensor.
 template <typename T, int NT>
-__device__ __forceinline__ void conv_epilogue_px(const ConvP& p, const f32x4 (&acc)[NT], int m, bool valid,
-                                                 int cb, const float (&bias)[NT * 4], int HoWo) {
-  if (!valid) return;
-  const int b = m / HoWo;
-  const int r = m - b * HoWo;
-  const int ho = r / p.Wo;
-  const int wo = r - ho * p.Wo;
+__device__ __forceinline__ void conv_epilogue_at(const ConvP& p, const f32x4 (&acc)[NT], int b, int ho, int wo,
+                                                 int cb, const float (&bias)[NT * 4]) {
   const size_t pix = ((size_t)b * p.Hop + ho + 1) * p.Wop + wo + 1;
   const size_t off = (pix * p.Cout + cb) * 2;
   float v[NT * 4];
@@ -165,5 +160,17 @@ __device__ __forceinline__ void conv_epilogue_px(const ConvP& p, const f32x4 (&a
     for (int q = 0; q < 4; ++q) o[q] = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
     *(u32x4*)(op + c * 16) = o;
   }
+}
+
+// flat output-pixel index m -> (image, row, column) by multiply-shift (p.mg_* from the host's fastdiv_magic; a runtime
+// '/' costs ~40 vector instructions, and vector instructions share the SIMD's issue slots with the MFMAs)
+template <typename T, int NT>
+__device__ __forceinline__ void conv_epilogue_px(const ConvP& p, const f32x4 (&acc)[NT], int m, bool valid,
+                                                 int cb, const float (&bias)[NT * 4], int HoWo) {
+  if (!valid) return;
+  const int b = fastdiv(m, p.mg_hw, p.sh_hw);
+  const int r = m - b * HoWo;
+  const int ho = fastdiv(r, p.mg_w, p.sh_w);
+  conv_epilogue_at<T, NT>(p, acc, b, ho, r - ho * p.Wo, cb, bias);
 }
 

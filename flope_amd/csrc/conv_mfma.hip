@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
       const int m = min(m0 + wpx * MT * 16 + pt * 16 + pcol, mend - 1);
-      const int b = m / HoWo, r = m - b * HoWo, ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int b = fastdiv(m, p.mg_hw, p.sh_hw), r = m - b * HoWo, ho = fastdiv(r, p.mg_w, p.sh_w), wo = r - ho * p.Wo;
       pi0[pt] = (b * p.Hip + ho * p.stride - R0) * p.Wip + wo * p.stride;
     }
   } else {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
     for (int i = 0; i < AP; ++i) {
       const int row = (i * 4 + wave) * 8 + (lane >> 3);
       const int m = min(m0 + row, mend - 1);
-      const int b = m / HoWo, r = m - b * HoWo, ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int b = fastdiv(m, p.mg_hw, p.sh_hw), r = m - b * HoWo, ho = fastdiv(r, p.mg_w, p.sh_w), wo = r - ho * p.Wo;
       const size_t pix = ((size_t)b * p.Hip + ho * p.stride) * p.Wip + wo * p.stride +
                          (p.ntaps == 1 ? p.Wip + 1 : 0);
       a_src[i] = (const char*)p.in + pix * p.Cin * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemP p) {
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) {
     const int m = m0 + wave * 64 + pt * 16 + r16;
-    conv_epilogue_px<T, NT>(q, acc[pt], img * HoWo + m, m < mend, cb, bias, HoWo);
+    if (m < mend) conv_epilogue_at<T, NT>(q, acc[pt], img, m / p.Wo, m % p.Wo, cb, bias);
   }
 }
 
