@@ -126,7 +126,8 @@ struct NaiveConvP {    // strict fp32 direct convolution on padded NHWC float te
 // Shared MFMA epilogue: one lane = one output pixel x (4*NT) consecutive channels.
 // acc + bias (+ residual) (ReLU) -> 16-bit, written as 16-byte NHWC stores into the
 // interior of the zero-bordered output tensor.
-template <typename T, int NT>
+// ADD_BIAS = false: the accumulators were initialised to the bias (conv_mfma), nothing to add here.
+template <typename T, int NT, bool ADD_BIAS = true>
 __device__ __forceinline__ void conv_epilogue_at(const ConvP& p, const f32x4 (&acc)[NT], int b, int ho, int wo,
                                                  int cb, const float (&bias)[NT * 4]) {
   const size_t pix = ((size_t)b * p.Hop + ho + 1) * p.Wop + wo + 1;
@@ -135,7 +136,7 @@ __device__ __forceinline__ void conv_epilogue_at(const ConvP& p, const f32x4 (&a
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[ct][q] + bias[ct * 4 + q];
+    for (int q = 0; q < 4; ++q) v[ct * 4 + q] = ADD_BIAS ? acc[ct][q] + bias[ct * 4 + q] : acc[ct][q];
   if (p.res) {
     const char* rp = (const char*)p.res + off;
 #pragma unroll
@@ -148,29 +149,28 @@ __device__ __forceinline__ void conv_epilogue_at(const ConvP& p, const f32x4 (&a
       }
     }
   }
-  if (p.relu) {
-#pragma unroll
-    for (int i = 0; i < NT * 4; ++i) v[i] = fmaxf(v[i], 0.f);
-  }
   char* op = (char*)p.out + off;
 #pragma unroll
   for (int c = 0; c < NT / 2; ++c) {
     u32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
+    for (int q = 0; q < 4; ++q) {
+      const unsigned w = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
+      o[q] = p.relu ? pk_relu16(w) : w;                    // ReLU on the packed pair (sign test is rounding-invariant)
+    }
     *(u32x4*)(op + c * 16) = o;
   }
 }
 
 // flat output-pixel index m -> (image, row, column) by multiply-shift (p.mg_* from the host's fastdiv_magic; a runtime
 // '/' costs ~40 vector instructions, and vector instructions share the SIMD's issue slots with the MFMAs)
-template <typename T, int NT>
+template <typename T, int NT, bool ADD_BIAS = true>
 __device__ __forceinline__ void conv_epilogue_px(const ConvP& p, const f32x4 (&acc)[NT], int m, bool valid,
                                                  int cb, const float (&bias)[NT * 4], int HoWo) {
   if (!valid) return;
   const int b = fastdiv(m, p.mg_hw, p.sh_hw);
   const int r = m - b * HoWo;
   const int ho = fastdiv(r, p.mg_w, p.sh_w);
-  conv_epilogue_at<T, NT>(p, acc, b, ho, r - ho * p.Wo, cb, bias);
+  conv_epilogue_at<T, NT, ADD_BIAS>(p, acc, b, ho, r - ho * p.Wo, cb, bias);
 }
 

@@ -123,11 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   const int wbase = (wch * NT * 16 + r16) * 128;
   const int xbase = (wpx * MT * 16 + pcol) * 128;
 
+  const int cb = ntile * BN + wch * NT * 16 + g * (4 * NT);
+  float bias[NT * 4];                          // accumulators start at the folded-BN bias
+#pragma unroll
+  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
 
   // ---- staging helpers (macros keep every array index a compile-time constant)
 #define ISSUE_B(step_, slot_)                                                                                  \
@@ -250,14 +254,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
 #undef LOAD_X
 
   // ---- epilogue: + bias (+ residual) (ReLU) -> 16-bit padded NHWC
-  const int cb = ntile * BN + wch * NT * 16 + g * (4 * NT);
-  float bias[NT * 4];
-#pragma unroll
-  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) {
     const int m = m0 + wpx * MT * 16 + pt * 16 + pcol;
-    conv_epilogue_px<T, NT>(p, acc[pt], m, m < mend, cb, bias, HoWo);
+    conv_epilogue_px<T, NT, false>(p, acc[pt], m, m < mend, cb, bias, HoWo);
   }
 }
 
