@@ -96,6 +96,10 @@ struct ConvP {
   int dbg;             // timing experiments only: bit0 skip weight staging, bit1 skip pixel staging, bit2 skip MFMA
   unsigned mg_hw, sh_hw, mg_w, sh_w;   // n / (Ho*Wo) and n / Wo as multiply-shift (host: fastdiv_magic), n < 2^31
   int total_tiles;     // conv_stag: persistent grid walks tiles blockIdx.x + k*gridDim.x < total_tiles
+  // conv_stag, folded downsample (layerX.0.conv2): out += W_ds . ds_in(2*ho, 2*wo) -- the block's 1x1 stride-2 shortcut
+  const void* ds_in;   // padded NHWC [B][ds_Hip][ds_Wip][ds_Cin] (the block input), nullptr = none
+  const void* ds_w;    // [ntile][ds_Cin/32 half-chunks][128 rows][32 k] conv_stag image
+  int ds_Hip, ds_Wip, ds_Cin;
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

@@ -45,7 +45,13 @@ __device__ __forceinline__ int tile_px_s(int c) { return c < 4 ? 2 * c : (c < 12
 // per workgroup instead of once per tile (it was ~300 of the ~1000 vector instructions a tile cost outside its
 // MFMAs -- with K = 576 those instructions were as expensive as the 288 MFMAs), 7 tiles per image divide the
 // 256 x 7 tiles of B = 256 evenly over 256 CUs, and m0 carries the tile's first padded OUTPUT row.
-template <typename T, int PT, int BN, bool RES, bool ROWS>
+// DSF (BN = 128, no residual input, one tile per workgroup, PT >= 4): the block's 1x1 stride-2 shortcut convolution
+// is folded into this kernel as extra K -- before the main loop, for every 64 input channels of the block input x,
+// the tile's 256 centre pixels x(2ho, 2wo) are gathered by LDS-DMA into patch buffer 1 (two 32-channel pixel tiles),
+// the matching double tile of shortcut weights goes into ring slot 2, and one double step of 32 MFMAs adds
+// W_ds . x to the same accumulators (which start at bias2 + bias_ds).  Saves the separate downsample launch, its
+// output write and this kernel's residual read; the shortcut sum is never rounded to 16 bits on the way.
+template <typename T, int PT, int BN, bool RES, bool ROWS, bool DSF = false>
 __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
   constexpr int BM = BN == 128 ? 256 : 512, GP = BM / 2, TILE_B = BN * 64;   // 8 / 4 KB weight tile per (half-chunk, tap)
@@ -259,6 +265,52 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         }
   }
   BARRIER();
+  if constexpr (DSF) {
+    static_assert(BN == 128 && !RES && !ROWS && PT >= 4, "folded downsample: 256 x 128 tiles, 32 KB patch buffers");
+    // this lane's two DMA source pixels (pieces rr*512 + wave*64 + lane: pixel slot = piece >> 2, 16-byte part = piece & 3)
+    const char* dsrc[2];
+    const size_t dpix = (size_t)p.ds_Cin * 2;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int q = rr * 512 + wave * 64 + lane, sl = q >> 2;
+      const int m = min(m0 + sl, mend - 1);
+      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+      dsrc[rr] = (const char*)p.ds_in + (((size_t)b_ * p.ds_Hip + 2 * ho_ + 1) * p.ds_Wip + 2 * wo_ + 1) * dpix +
+                 (((q & 3) ^ ((sl >> 2) & 3)) << 4);
+    }
+    int xds[MT];                                 // fragment offsets inside a gathered pixel tile (slot-linear, same swizzle)
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) {
+      const int sl = group * GP + wpx * 64 + pt * 16 + pcol;
+      xds[pt] = PATCH_B + (sl << 6) + ((g ^ ((sl >> 2) & 3)) << 4);
+    }
+    const char* const dw_base = (const char*)p.ds_w + (size_t)ntile * (p.ds_Cin / 32) * TILE_B + wave * 1024 + lane16;
+    for (int j = 0; j < p.ds_Cin / 64; ++j) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+          GLDS16(dsrc[rr] + (2 * j + t) * 64, Ps + PATCH_B + t * 16384 + (rr * 512 + wave * 64) * 16);
+#pragma unroll
+      for (int o = 0; o < TG; ++o) GLDS16(dw_base + (size_t)j * DT_B + o * 8192, Bs + 2 * DT_B + o * 8192 + wave * 1024);
+      WAIT_VM(0);
+      BARRIER();
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        wf[0][ct] = *(const frag*)(smem + wbase + 2 * DT_B + ct * 1024);
+        wf[1][ct] = *(const frag*)(smem + wbase + 2 * DT_B + TILE_B + ct * 1024);
+      }
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) {
+        xf[0][pt] = *(const frag*)(smem + xds[pt]);
+        xf[1][pt] = *(const frag*)(smem + xds[pt] + 16384);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MFMAS();
+      BARRIER();                                 // buffer 1 / slot 2 are free again (next j, or the main loop's step 0)
+    }
+  }
   if (group == 1) BARRIER();                   // group B runs one phase behind group A
 
   // Every wave executes the SAME stream per double step D (two (half-chunk, tap) pairs u = 2D, 2D+1 of the
@@ -437,6 +489,10 @@ static hipError_t stag_attr() {
   A(2, 128) A(3, 128) A(4, 128) A(5, 128) A(6, 128) A(8, 128) A(2, 64) A(3, 64) A(4, 64) A(5, 64) A(6, 64) A(8, 64)
 #undef A
 #define A(PT_) \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 128, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A(4) A(5) A(6) A(8)
+#undef A
+#define A(PT_) \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_stag_kernel<T, PT_, 64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A(3) A(5) A(6) A(8)
@@ -462,6 +518,16 @@ static void stag_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hip
     default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, BN, RES, false>), grid, block, lds, st, p); break;
   }
 }
+template <typename T>
+static void stag_dsf_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
+  const dim3 grid(grid_blocks), block(512);
+  switch (pt) {
+    case 4: hipLaunchKernelGGL((conv_stag_kernel<T, 4, 128, false, false, true>), grid, block, lds, st, p); break;
+    case 5: hipLaunchKernelGGL((conv_stag_kernel<T, 5, 128, false, false, true>), grid, block, lds, st, p); break;
+    case 6: hipLaunchKernelGGL((conv_stag_kernel<T, 6, 128, false, false, true>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_stag_kernel<T, 8, 128, false, false, true>), grid, block, lds, st, p); break;
+  }
+}
 template <typename T, bool RES>
 static void stag_rows_launch(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
   const dim3 grid(grid_blocks), block(512);
@@ -480,7 +546,10 @@ extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks
   hipStream_t st = (hipStream_t)stream;
   const int pt = p->patch_rows_max;
 #define GO(T, BN_) (p->res ? stag_launch<T, BN_, true>(*p, pt, grid_blocks, lds, st) : stag_launch<T, BN_, false>(*p, pt, grid_blocks, lds, st))
-  if (p->per_image == 2) {          // ROWS geometry: 8-row bands of one image (p->tiles_per_image bands per image)
+  if (p->ds_in) {                   // folded 1x1 stride-2 shortcut: one tile per workgroup, no residual input
+    if (p->Cout < 128 || p->res || pt < 4 || pt == 7 || grid_blocks != p->total_tiles || p->ds_Cin % 64 || !p->ds_w) return (int)hipErrorInvalidValue;
+    if (dtype == 0) stag_dsf_launch<bf16_t>(*p, pt, grid_blocks, lds, st); else stag_dsf_launch<f16_t>(*p, pt, grid_blocks, lds, st);
+  } else if (p->per_image == 2) {          // ROWS geometry: 8-row bands of one image (p->tiles_per_image bands per image)
     if (p->Cout != 64 || p->Wo > 64 || p->Ho % 8 || (pt != 3 && pt != 5 && pt != 6 && pt != 8) || ((pt & 1) && p->Cin != 64)) return (int)hipErrorInvalidValue;
     if (dtype == 0) { if (p->res) stag_rows_launch<bf16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<bf16_t, false>(*p, pt, grid_blocks, lds, st); }
     else            { if (p->res) stag_rows_launch<f16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<f16_t, false>(*p, pt, grid_blocks, lds, st); }

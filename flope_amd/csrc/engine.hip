@@ -61,6 +61,11 @@ struct Conv {
   int stag = 0, stag_patch_bytes = 0; size_t stag_lds = 0;
   float* w_naive = nullptr;    // [ky][kx][ci][cout]
   float* bias = nullptr;
+  // folded shortcut (conv_stag DSF): on a 1x1 downsample conv, folded = 1 means "computed inside layerX.0.conv2";
+  // on that conv2, ds_conv is the index of the downsample and bias_fused = bias + bias of the downsample
+  int folded = 0, ds_conv = -1;
+  void* w_ds_stag = nullptr;   // downsample conv only: its weights as a conv_stag image
+  float* bias_fused = nullptr; // conv2 only
 };
 
 struct Buf { void* ptr = nullptr; size_t bytes = 0; int C = 0, h = 0, w = 0; };
@@ -82,7 +87,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
@@ -291,7 +296,19 @@ extern "C" const char* flope_version(void) { return "flope_amd 0.1 (gfx950; mfma
 extern "C" const char* flope_last_error(flope_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
 static int rebuild_plan(flope_engine* e) {
-  for (Conv& c : e->convs) plan_conv(e, c);
+  for (Conv& c : e->convs) { plan_conv(e, c); c.folded = 0; c.ds_conv = -1; }
+  // fold each block's 1x1 stride-2 shortcut into the conv2 that consumes it when that conv2 runs on conv_stag 256x128
+  // tiles with >= 32 KB patch buffers (one gathered 64-channel pixel tile pair fits one buffer)
+  if (e->opt_dsfuse && e->dtype != FLOPE_DT_F32)
+    for (size_t i = 0; i + 1 < e->convs.size(); ++i) {
+      Conv& cd = e->convs[i];
+      Conv& c2 = e->convs[i + 1];
+      if (cd.k == 1 && c2.k == 3 && c2.res_buf == cd.out_buf && c2.stag == 1 && c2.cout >= 128 && c2.stag_patch_bytes >= 4 &&
+          c2.stag_patch_bytes != 7 && cd.cin % 64 == 0 && cd.stride == 2) {
+        cd.folded = 1;
+        c2.ds_conv = (int)i;
+      }
+    }
   return 0;
 }
 
@@ -435,6 +452,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
+  else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
   else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
   else if (!strcmp(name, "fuse_stem")) { prev = e->opt_fuse_stem; e->opt_fuse_stem = value != 0; return prev; }
@@ -462,6 +480,7 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
     ts.t[names[i]] = std::make_pair(host_ptrs[i], shp);
   }
   std::vector<float> wf, bf;
+  std::vector<std::vector<float>> host_bias;   // folded-BN bias of every conv, in e->convs order
   int rc;
   // stem
   if ((rc = fold(e, ts, "base.conv1", "base.bn1", 64, 3, 7, &wf, &bf)) != 0) return rc;
@@ -475,8 +494,17 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
     else {
       if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc;
       if (c.k == 3 && c.stride == 1 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
+      if (c.k == 1 && c.cout >= 128 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32_1x1(wf, c.cout, c.cin, e->dtype), &c.w_ds_stag)) != 0) return rc;
     }
+    host_bias.push_back(bf);
   }
+  // conv2 of a block with a shortcut conv: bias2 + bias_ds for the folded form (whether or not the plan uses it)
+  for (size_t i = 0; i + 1 < e->convs.size(); ++i)
+    if (e->convs[i].k == 1 && e->convs[i + 1].res_buf == e->convs[i].out_buf) {
+      std::vector<float> sum = host_bias[i + 1];
+      for (size_t j = 0; j < sum.size(); ++j) sum[j] += host_bias[i][j];
+      if ((rc = upload(e, sum, (void**)&e->convs[i + 1].bias_fused)) != 0) return rc;
+    }
   // head (fp32 as stored)
   const float* w1 = ts.get(e, "base.fc.0.weight", {e->bod, 512}, &rc); if (!w1) return rc;
   const float* b1 = ts.get(e, "base.fc.0.bias", {e->bod}, &rc); if (!b1) return rc;
@@ -540,6 +568,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
     K_TRY(e, "maxpool", flope_maxpool_launch(&pp, dt, stream));
   }
   for (const Conv& c : e->convs) {
+    if (c.folded) { SMARK(); continue; }             // computed inside the next launch (conv_stag DSF)
     if (dt == FLOPE_DT_F32) {
       NaiveConvP p; memset(&p, 0, sizeof(p));
       p.in = (const float*)vb[c.in_buf].ptr; p.out = (float*)vb[c.out_buf].ptr;
@@ -555,10 +584,15 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       const int sbm = c.cout == 64 ? 512 : 256;
       p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + sbm - 1) / sbm; p.ntiles = c.cout == 64 ? 1 : c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
       p.total_tiles = p.mtiles * p.ntiles;
+      if (c.ds_conv >= 0) {
+        const Conv& cd = e->convs[c.ds_conv];
+        p.res = nullptr; p.bias = c.bias_fused;
+        p.ds_in = vb[cd.in_buf].ptr; p.ds_w = cd.w_ds_stag; p.ds_Hip = cd.hin + 2; p.ds_Wip = cd.win + 2; p.ds_Cin = cd.cin;
+      }
       if (c.stag == 2) { p.per_image = 2; p.tiles_per_image = c.hout / 8; p.mtiles = batch * p.tiles_per_image; p.total_tiles = p.mtiles; }
       // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile); the
       // row-band kernel is always persistent and shares the CUs with the other batch slices in flight
-      int gridb = e->opt_persist ? std::min(p.total_tiles, e->num_cus) : p.total_tiles;
+      int gridb = (e->opt_persist && c.ds_conv < 0) ? std::min(p.total_tiles, e->num_cus) : p.total_tiles;
       if (c.stag == 2)    // this slice's share of the CUs (slices in flight together cover the chip once)
         gridb = std::min(p.total_tiles, e->opt_rows_grid > 0 ? e->opt_rows_grid
                                           : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
@@ -674,7 +708,12 @@ extern "C" double flope_forward_flops(flope_handle e, int batch) {
 }
 
 static int head_launches(const flope_engine* e) { return (e->opt_fuse_stem && e->dtype != FLOPE_DT_F32) ? 1 : 3; }
-extern "C" int flope_forward_launches(flope_handle e) { return e ? (int)e->convs.size() + 3 + head_launches(e) : 0; }
+extern "C" int flope_forward_launches(flope_handle e) {
+  if (!e) return 0;
+  int n = (int)e->convs.size() + 3 + head_launches(e);
+  for (const Conv& c : e->convs) n -= c.folded;
+  return n;
+}
 
 // profile mode ("profile" option): per-launch GPU time of the LAST flope_forward, from HIP
 // events recorded on the caller's stream around every launch.  Synchronises on the last event.
@@ -713,6 +752,12 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
+    if (c.folded) { s = c.name + "|(folded into conv2)"; f = 0.0; }
+    if (c.ds_conv >= 0) {
+      const Conv& cd = e->convs[c.ds_conv];
+      s = c.name + "+shortcut|" + k;
+      f += 2.0 * cd.hout * cd.wout * cd.cout * cd.cin;
+    }
   } else if (idx == 3 + nc) s = "avgpool|avgpool_kernel";
   else if (idx == 4 + nc) { s = "fc1|fc1_kernel"; f = 2.0 * 512 * e->bod; }
   else { s = "fc_rot+procrustes|fc2_procrustes_kernel"; f = 2.0 * 9 * e->bod; }
@@ -729,6 +774,8 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
   snprintf(line, sizeof line, "stem: tiles/img=%d rows=%d lds=%zu\n", e->stem_tiles, e->stem_rows, e->stem_lds);
   s += line;
   for (const Conv& c : e->convs) {
+    if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
+    if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);

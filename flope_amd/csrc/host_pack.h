@@ -107,6 +107,25 @@ inline std::vector<uint16_t> pack_conv32(const std::vector<float>& wf, int cout,
   return out;
 }
 
+// 1x1 weights wf[cout][cin] in the conv_stag image: [ntile (cout/128)][hc][128 rows][32 k] (one tap per half-chunk)
+inline std::vector<uint16_t> pack_conv32_1x1(const std::vector<float>& wf, int cout, int cin, int dtype) {
+  static const int h[4] = {0, 2, 3, 1};
+  const int BN = 128, ntiles = cout / BN, nhc = cin / 32;
+  std::vector<uint16_t> out((size_t)cout * cin);
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int hc = 0; hc < nhc; ++hc) {
+      const size_t tile = ((size_t)nt * nhc + hc) * BN * 32;
+      for (int rl = 0; rl < BN; ++rl) {
+        const int co = nt * BN + lds_row_to_channel(rl);
+        for (int kk = 0; kk < 32; ++kk) {
+          const int slot = (kk >> 3) ^ h[(rl >> 2) & 3];
+          out[tile + (size_t)rl * 32 + slot * 8 + (kk & 7)] = cvt16(wf[(size_t)co * cin + hc * 32 + kk], dtype);
+        }
+      }
+    }
+  return out;
+}
+
 // stem weights wf[64][3][7][7] -> [7 ky][64 rows][32 k = kx*4 + c] images (64-byte rows,
 // slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1})
 inline std::vector<uint16_t> pack_stem(const std::vector<float>& wf, int dtype) {

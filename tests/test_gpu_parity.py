@@ -56,7 +56,7 @@ def test_f32_strict_mode_every_stage(state_dict, H, W, B):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("opts", [dict(patch=1, bm256=1, nbuf=3, fuse_stem=1, stag=2), dict(patch=0, bm256=0, nbuf=3, fuse_stem=0, stag=0),
-                                  dict(patch=1, bm256=0, nbuf=2, fuse_stem=0, stag=0), dict(patch=0, bm256=1, nbuf=2, fuse_stem=1, stag=1)])
+                                  dict(patch=1, bm256=0, nbuf=2, fuse_stem=0, stag=0), dict(patch=0, bm256=1, nbuf=2, fuse_stem=1, stag=1, dsfuse=0)])
 @pytest.mark.parametrize("H,W,B", [(224, 224, 5), (96, 80, 3), (65, 71, 2)])
 def test_mfma_path_every_stage_vs_emulating_oracle(state_dict, dtype, opts, H, W, B):
     torch.manual_seed(11)
@@ -87,6 +87,8 @@ def test_layer1_row_band_kernel_every_stage(state_dict, H, W, B, streams):
     emu = O.forward_stages_emulated(state_dict, x, torch.float16)
     e = _engine(state_dict, H, W, B, "f16", stag=3, streams=streams)
     assert "8-row bands" in e.describe_plan()
+    if (H, W) == (224, 224):
+        assert e.describe_plan().count("shortcut folded in") == 3     # layer2/3/4 .0.conv2 carry their 1x1 stride-2 shortcut
     r9, _ = _run(e, x)
     for s in STAGES:
         if s == "stem":
