@@ -568,7 +568,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
     K_TRY(e, "maxpool", flope_maxpool_launch(&pp, dt, stream));
   }
   for (const Conv& c : e->convs) {
-    if (c.folded) { SMARK(); continue; }             // computed inside the next launch (conv_stag DSF)
+    if (c.folded) continue;                          // computed inside the next launch (conv_stag DSF)
     if (dt == FLOPE_DT_F32) {
       NaiveConvP p; memset(&p, 0, sizeof(p));
       p.in = (const float*)vb[c.in_buf].ptr; p.out = (float*)vb[c.out_buf].ptr;
@@ -729,7 +729,9 @@ extern "C" int flope_profile_read(flope_handle e, float* ms_out, int cap) {
 // launch idx of flope_forward: "layer|kernel" label and its algorithmic FLOPs for `batch` crops
 extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name, int name_cap, double* flops) {
   if (!e || !name || name_cap < 1 || !flops) return fail(e, FLOPE_EINVAL, "flope_launch_info: NULL argument");
-  const int nc = (int)e->convs.size();
+  std::vector<int> live;                             // convs that are launched (folded shortcuts are not)
+  for (size_t i = 0; i < e->convs.size(); ++i) if (!e->convs[i].folded) live.push_back((int)i);
+  const int nc = (int)live.size();
   const int nh = head_launches(e);
   if (idx < 0 || idx >= nc + 3 + nh) return fail(e, FLOPE_EINVAL, "flope_launch_info: bad index");
   const bool f32 = e->dtype == FLOPE_DT_F32;
@@ -744,7 +746,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
   idx += 3 - nh;
   if (idx < 3) { /* named above */ }
   else if (idx < 3 + nc) {
-    const Conv& c = e->convs[idx - 3];
+    const Conv& c = e->convs[live[idx - 3]];
     int BM, BN; tile_dims(c.cfg, &BM, &BN);
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
@@ -752,7 +754,6 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
-    if (c.folded) { s = c.name + "|(folded into conv2)"; f = 0.0; }
     if (c.ds_conv >= 0) {
       const Conv& cd = e->convs[c.ds_conv];
       s = c.name + "+shortcut|" + k;

@@ -15,8 +15,8 @@ FWD = 20.0   # forwards in the kernel-trace run (tools/profile_target.py 20), 4 
 
 def fam(k):
     if "conv_stag" in k and "Li64E" in k: return "conv_stag<8 rows x 64> (layer 1)", 59.19
-    if "conv_stag" in k: return "conv_stag<256x128> (layers 2-4, 3x3 s1)", 59.19
-    if "conv_mfma" in k: return "conv_mfma<128x128,gather> (3x3 s2 + 1x1 s2)", (3 * 29.59 + 3 * 3.29) / 6
+    if "conv_stag" in k: return "conv_stag<256x128> (layers 2-4, 3x3 s1; three of nine carry the folded 1x1 shortcut)", 59.19 + 3.29 / 3
+    if "conv_mfma" in k: return "conv_mfma<128x128,gather> (3x3 s2)", 29.59
     if "stem_pool" in k: return "stem_pool (conv1 7x7 s2 + bn + relu + maxpool)", 60.42
     if "fc1" in k: return "fc1 (fc.0 + ReLU, f32 MFMA)", 0.537
     if "fc2" in k: return "fc2_procrustes", 0.0094
