@@ -528,7 +528,10 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
 // trunk: crop batch -> last BasicBlock output + pooled features
 // One slice [start, start+batch) of the crop batch through the trunk + fc.0 on `stream`.  Every tensor is
 // batch-major, so a slice is just an offset view of the same buffers.
-static int run_slice(flope_engine* e, const void* x_dev, int in_format, int start, int batch, void* stream, bool marks) {
+// head: fc_rot + Procrustes of this slice on the slice's own stream (so a slice's head overlaps the other slice's
+// trunk instead of running after the join); r9_dev / R_dev are the caller's full-batch buffers, head = false skips it.
+static int run_slice(flope_engine* e, const void* x_dev, int in_format, int start, int batch, void* stream, bool marks,
+                     bool head, float* r9_dev, float* R_dev) {
   const int dt = e->dtype;
   const size_t in_img_bytes = (size_t)e->H * e->W * 3 * (in_format == 0 ? 4 : (in_format == 3 ? 1 : 2));
   const char* x = (const char*)x_dev + (size_t)start * in_img_bytes;
@@ -611,6 +614,13 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
   K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
   SMARK();
   K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->b1, hidden, batch, 512, e->bod, stream));
+  if (head) {
+    SMARK();
+    float* r9 = (r9_dev ? r9_dev : e->r9_scratch) + (size_t)start * 9;
+    K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(hidden, e->W2, e->b2, r9, R_dev ? R_dev + (size_t)start * 9 : nullptr,
+                                                                batch, e->bod, stream));
+  }
+  SMARK();
 #undef SMARK
   return FLOPE_OK;
 }
@@ -619,7 +629,8 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
 // crops are split into two halves that run the same launch sequence on two internal streams forked from /
 // joined to the caller's stream: the tail of one half's kernel (the last, partly filled round of
 // workgroups -- up to 24 % of a launch at B = 256) overlaps the head of the other half's.
-static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batch, void* stream) {
+static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batch, void* stream, bool head = false,
+                     float* r9_dev = nullptr, float* R_dev = nullptr) {
   if (!e->weights_loaded) return fail(e, FLOPE_ESTATE, "forward before flope_load_weights");
   if (!x_dev) return fail(e, FLOPE_EINVAL, "forward: x_dev is NULL");
   if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "forward: batch must be within 1..max_batch");
@@ -631,7 +642,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
   e->cur_slices = ns;
   e->cur_batch = batch;
-  if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true);
+  if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true, head, r9_dev, R_dev);
   hipStream_t user = (hipStream_t)stream;
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
   // slices are launched layer-interleaved?  No: each slice's whole sequence goes to its own stream; the
@@ -650,7 +661,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
       first = std::max(1, std::min(batch - 1, first));
       start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
     }
-    int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false);
+    int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false, head, r9_dev, R_dev);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(e->ev_join[s], e->side[s]));
   }
@@ -661,12 +672,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
 extern "C" int flope_forward(flope_handle e, const void* x_dev, int in_format, int batch, float* r9_dev, float* R_dev,
                              void* stream) {
   if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_forward: NULL handle");
-  int rc = run_trunk(e, x_dev, in_format, batch, stream);
-  if (rc) return rc;
-  MARK(e, stream);
-  K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(e->hidden, e->W2, e->b2, r9_dev ? r9_dev : e->r9_scratch, R_dev, batch, e->bod, stream));
-  MARK(e, stream);
-  return FLOPE_OK;
+  return run_trunk(e, x_dev, in_format, batch, stream, true, r9_dev, R_dev);
 }
 
 extern "C" int flope_extract_features(flope_handle e, const void* x_dev, int in_format, int batch, float* feat_dev,

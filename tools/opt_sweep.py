@@ -6,7 +6,7 @@ sd = synthetic_state_dict(0)
 B = 256
 x = torch.rand(B, 224, 224, 3).to(torch.float16).cuda()
 R = torch.empty(B, 9, device="cuda")
-combos = [dict(), dict(dsfuse=0), dict(), dict(dsfuse=0), dict(streams=1), dict(streams=1, dsfuse=0)]
+combos = [dict(), dict(), dict()]
 for opts in combos:
     e = PoseEngine(224, 224, B, "f16")
     for k, v in opts.items(): e.set_option(k, v)
