@@ -158,6 +158,21 @@ def test_full_batch_properties_cfg2(state_dict):
     e.close()
 
 
+@pytest.mark.parametrize("B", [131, 200, 255])
+def test_slice_split_is_invisible(state_dict, B):
+    """The internal two-slice split (3/8 : 5/8 on multiples of 8 images, row-band grids proportional to the slice) must
+    not change a single bit relative to one slice, for batches that do not divide nicely."""
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 224, 224, 3, generator=g).to(torch.float16).cuda()
+    outs = []
+    for streams in (1, 2):
+        e = _engine(state_dict, 224, 224, 256, "f16", streams=streams)
+        r9, R = e.forward(x)
+        outs.append((r9.clone(), R.clone()))
+        e.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_procrustes_yaw_compose_kernels():
     from flope_amd import engine as E
     g = torch.Generator().manual_seed(14)
