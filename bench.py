@@ -105,13 +105,10 @@ def main():
         return eng, x, (2 if dtype == "f16" else 1)
 
     def run_steps(eng, x, fmt, n, poses, R, xyz):
-        lib, stream = eng.lib, torch.cuda.current_stream(dev).cuda_stream
         for i in range(n):
-            eng.forward_into(x, fmt, None, R)
-            # yaw-null + [R|t] assembly straight into this step's slice of the pose buffer
-            rc = lib.flope_compose_pose(R.data_ptr(), xyz.data_ptr(), B, 1, poses[i % poses.shape[0]].data_ptr(), stream)
-            if rc:
-                raise RuntimeError("compose_pose failed")
+            # forward + Procrustes + yaw-null + [R|t] assembly (flope_forward_poses) straight into this step's slice of
+            # the pose buffer; R is kept too (the parity sample below reads it)
+            eng.forward_poses_into(x, fmt, xyz, True, poses[i % poses.shape[0]], R)
 
     def measure(dtype):
         eng, x, fmt = build(dtype)

@@ -25,6 +25,7 @@ SIGNATURES = {
     "flope_last_error": (C.c_char_p, [_P]),
     "flope_load_weights": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_I), C.POINTER(_P)]),
     "flope_forward": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "flope_forward_poses": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "flope_extract_features": (_I, [_P, _P, _I, _I, _P, _P]),
     "flope_procrustes": (_I, [_P, _P, _I, _P]),
     "flope_nullify_yaw": (_I, [_P, _P, _I, _P]),

@@ -25,7 +25,7 @@ extern "C" int flope_stem_launch(const StemP* p, int dtype, size_t lds, void* st
 extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream);
 extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, int w, int C, int dtype, void* stream);
 extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* b1, float* hidden, int B, int K, int N, void* stream);
-extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, void* stream);
+extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, const float* xyz, int nullify, float* Rt, void* stream);
 extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
@@ -530,8 +530,10 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
 // batch-major, so a slice is just an offset view of the same buffers.
 // head: fc_rot + Procrustes of this slice on the slice's own stream (so a slice's head overlaps the other slice's
 // trunk instead of running after the join); r9_dev / R_dev are the caller's full-batch buffers, head = false skips it.
+struct PoseOut { const float* xyz = nullptr; int nullify = 0; float* Rt = nullptr; };   // optional [B,16] pose assembly
+
 static int run_slice(flope_engine* e, const void* x_dev, int in_format, int start, int batch, void* stream, bool marks,
-                     bool head, float* r9_dev, float* R_dev) {
+                     bool head, float* r9_dev, float* R_dev, const PoseOut& po = PoseOut()) {
   const int dt = e->dtype;
   const size_t in_img_bytes = (size_t)e->H * e->W * 3 * (in_format == 0 ? 4 : (in_format == 3 ? 1 : 2));
   const char* x = (const char*)x_dev + (size_t)start * in_img_bytes;
@@ -618,7 +620,8 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
     SMARK();
     float* r9 = (r9_dev ? r9_dev : e->r9_scratch) + (size_t)start * 9;
     K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(hidden, e->W2, e->b2, r9, R_dev ? R_dev + (size_t)start * 9 : nullptr,
-                                                                batch, e->bod, stream));
+                                                                batch, e->bod, po.xyz ? po.xyz + (size_t)start * 3 : nullptr, po.nullify,
+                                                                po.Rt ? po.Rt + (size_t)start * 16 : nullptr, stream));
   }
   SMARK();
 #undef SMARK
@@ -630,7 +633,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
 // joined to the caller's stream: the tail of one half's kernel (the last, partly filled round of
 // workgroups -- up to 24 % of a launch at B = 256) overlaps the head of the other half's.
 static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batch, void* stream, bool head = false,
-                     float* r9_dev = nullptr, float* R_dev = nullptr) {
+                     float* r9_dev = nullptr, float* R_dev = nullptr, const PoseOut& po = PoseOut()) {
   if (!e->weights_loaded) return fail(e, FLOPE_ESTATE, "forward before flope_load_weights");
   if (!x_dev) return fail(e, FLOPE_EINVAL, "forward: x_dev is NULL");
   if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "forward: batch must be within 1..max_batch");
@@ -642,7 +645,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
   e->cur_slices = ns;
   e->cur_batch = batch;
-  if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true, head, r9_dev, R_dev);
+  if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true, head, r9_dev, R_dev, po);
   hipStream_t user = (hipStream_t)stream;
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
   // slices are launched layer-interleaved?  No: each slice's whole sequence goes to its own stream; the
@@ -661,7 +664,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
       first = std::max(1, std::min(batch - 1, first));
       start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
     }
-    int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false, head, r9_dev, R_dev);
+    int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false, head, r9_dev, R_dev, po);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(e->ev_join[s], e->side[s]));
   }
@@ -673,6 +676,14 @@ extern "C" int flope_forward(flope_handle e, const void* x_dev, int in_format, i
                              void* stream) {
   if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_forward: NULL handle");
   return run_trunk(e, x_dev, in_format, batch, stream, true, r9_dev, R_dev);
+}
+
+extern "C" int flope_forward_poses(flope_handle e, const void* x_dev, int in_format, int batch, const float* xyz_dev,
+                                   int nullify_yaw, float* r9_dev, float* R_dev, float* Rt_dev, void* stream) {
+  if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_forward_poses: NULL handle");
+  if (!Rt_dev) return fail(e, FLOPE_EINVAL, "flope_forward_poses: Rt_dev is NULL");
+  PoseOut po; po.xyz = xyz_dev; po.nullify = nullify_yaw != 0; po.Rt = Rt_dev;
+  return run_trunk(e, x_dev, in_format, batch, stream, true, r9_dev, R_dev, po);
 }
 
 extern "C" int flope_extract_features(flope_handle e, const void* x_dev, int in_format, int batch, float* feat_dev,

@@ -212,10 +212,13 @@ extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float*
 }
 
 // fc_rot + Procrustes: one wave per image.
+// Optional pose assembly in the same launch (fast_pose_predictor.py:131-144): Rt_out [B,16] = [[R', xyz],[0,0,0,1]] with
+// R' = yaw-nullified R when `nullify`; xyz [B,3] may be NULL (zeros).
 __global__ __launch_bounds__(256) void fc2_procrustes_kernel(const float* __restrict__ hidden,
                                                              const float* __restrict__ W2,
                                                              const float* __restrict__ b2, float* r9_out,
-                                                             float* R_out, int B, int K) {
+                                                             float* R_out, int B, int K, const float* xyz,
+                                                             int nullify, float* Rt_out) {
   const int lane = threadIdx.x & 63;
   const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (img >= B) return;
@@ -249,17 +252,30 @@ __global__ __launch_bounds__(256) void fc2_procrustes_kernel(const float* __rest
     for (int j = 0; j < 9; ++j) M[j] = acc[j] + b2[j];
     if (r9_out)
       for (int j = 0; j < 9; ++j) r9_out[(size_t)img * 9 + j] = M[j];
-    if (R_out) {
+    if (R_out || Rt_out) {
       procrustes3x3(M, R);
-      for (int j = 0; j < 9; ++j) R_out[(size_t)img * 9 + j] = R[j];
+      if (R_out)
+        for (int j = 0; j < 9; ++j) R_out[(size_t)img * 9 + j] = R[j];
+      if (Rt_out) {
+        float o[9];
+        if (nullify) nullify_yaw3x3(R, o);
+        else for (int j = 0; j < 9; ++j) o[j] = R[j];
+        float* t = Rt_out + (size_t)img * 16;
+        for (int a = 0; a < 3; ++a) {
+          for (int c = 0; c < 3; ++c) t[a * 4 + c] = o[a * 3 + c];
+          t[a * 4 + 3] = xyz ? xyz[(size_t)img * 3 + a] : 0.f;
+        }
+        t[12] = 0.f; t[13] = 0.f; t[14] = 0.f; t[15] = 1.f;
+      }
     }
   }
 }
 
 extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9,
-                                           float* R, int B, int K, void* stream) {
+                                           float* R, int B, int K, const float* xyz, int nullify, float* Rt,
+                                           void* stream) {
   hipLaunchKernelGGL(fc2_procrustes_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden, W2, b2, r9,
-                     R, B, K);
+                     R, B, K, xyz, nullify, Rt);
   return (int)hipGetLastError();
 }
 

@@ -122,6 +122,14 @@ class PoseEngine:
                                     R.data_ptr() if R is not None else None, _stream_ptr(self.device))
         _lib.check(rc, self.handle)
 
+    def forward_poses_into(self, x: torch.Tensor, fmt: int, xyz: torch.Tensor | None, nullify: bool, Rt: torch.Tensor,
+                           R: torch.Tensor | None = None) -> None:
+        """Allocation-free: crops -> [B,16] poses (Procrustes, optional yaw-null, Rt assembly in the head kernel)."""
+        rc = self.lib.flope_forward_poses(self.handle, x.data_ptr(), fmt, x.shape[0],
+                                          xyz.data_ptr() if xyz is not None else None, int(bool(nullify)), None,
+                                          R.data_ptr() if R is not None else None, Rt.data_ptr(), _stream_ptr(self.device))
+        _lib.check(rc, self.handle)
+
     def extract_features(self, x: torch.Tensor) -> torch.Tensor:
         fmt = self._check_input(x)
         x = x.contiguous()

@@ -102,6 +102,13 @@ int flope_nullify_yaw(const float* R_dev, float* out_dev, int n, void* stream);
 int flope_compose_pose(const float* R_dev, const float* xyz_dev, int n, int nullify_yaw,
                        float* Rt_dev, void* stream);
 
+/* flope_forward + flope_compose_pose in one launch sequence: the head kernel that solves the
+ * Procrustes problem also nullifies the yaw (if asked) and writes Rt = [[R', xyz],[0,0,0,1]]
+ * as float32 [batch,16].  xyz_dev float32 [batch,3] or NULL (zeros); r9_dev / R_dev optional. */
+int flope_forward_poses(flope_handle h, const void* x_dev, int in_format, int batch,
+                        const float* xyz_dev, int nullify_yaw, float* r9_dev, float* R_dev,
+                        float* Rt_dev, void* stream);
+
 /* Crop-batch assembly (4 copies in the reference: fast_pose_predictor.py:108-123,
  * pose_predictor.py:138-153, scripts/test_posenet.py:124-140,
  * scripts/generate_metrics_utils.py:17-35): for each square box

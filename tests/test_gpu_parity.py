@@ -173,6 +173,28 @@ def test_slice_split_is_invisible(state_dict, B):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_forward_poses_equals_forward_plus_compose(state_dict):
+    """flope_forward_poses (pose assembly inside the head kernel) == flope_forward followed by flope_compose_pose."""
+    from flope_amd import engine as E
+    B = 70
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 224, 224, 3, generator=g).to(torch.float16).cuda()
+    xyz = torch.rand(B, 3, generator=g).cuda()
+    e = _engine(state_dict, 224, 224, B, "f16")
+    _, R = e.forward(x)
+    for nullify in (True, False):
+        ref = E.compose_pose(R, xyz, nullify=nullify)
+        Rt = torch.empty(B, 16, device="cuda")
+        R2 = torch.empty(B, 9, device="cuda")
+        e.forward_poses_into(x, 2, xyz, nullify, Rt, R2)
+        assert torch.equal(Rt.view(B, 4, 4), ref) and torch.equal(R2.view(B, 3, 3), R)
+    Rt0 = torch.empty(B, 16, device="cuda")
+    e.forward_poses_into(x, 2, None, False, Rt0)                      # no translation: zeros
+    assert torch.equal(Rt0.view(B, 4, 4)[:, :3, 3], torch.zeros(B, 3, device="cuda"))
+    assert torch.equal(Rt0.view(B, 4, 4)[:, :3, :3], R)
+    e.close()
+
+
 def test_procrustes_yaw_compose_kernels():
     from flope_amd import engine as E
     g = torch.Generator().manual_seed(14)
