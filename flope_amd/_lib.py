@@ -58,6 +58,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles the HIP runtime, and the process must end up with ONE runtime instance -- loading
+    # this library before torch left its hipGetDeviceCount without devices (seen with build() then smoke() in one process)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"flope_amd: {LIB_PATH} is missing -- build it with `make` (or "
