@@ -597,7 +597,9 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       if (c.stag == 2) { p.per_image = 2; p.tiles_per_image = c.hout / 8; p.mtiles = batch * p.tiles_per_image; p.total_tiles = p.mtiles; }
       // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile); the
       // row-band kernel is always persistent and shares the CUs with the other batch slices in flight
-      int gridb = (e->opt_persist && c.ds_conv < 0) ? std::min(p.total_tiles, e->num_cus) : p.total_tiles;
+      int gridb = (e->opt_persist && c.ds_conv < 0)
+                      ? std::min(p.total_tiles, std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))))
+                      : p.total_tiles;
       if (c.stag == 2)    // this slice's share of the CUs (slices in flight together cover the chip once)
         gridb = std::min(p.total_tiles, e->opt_rows_grid > 0 ? e->opt_rows_grid
                                           : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
