@@ -12,6 +12,7 @@
 // LDS (aliasing the weight/input staging), max-pools there and writes 16-byte NHWC vectors.
 // The one-pixel conv halo is recomputed by the neighbour tile (289 conv px per 256 consumed).
 #include "common.h"
+#include <type_traits>
 
 #define GLDS16(gptr, lptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),          \
@@ -61,66 +62,72 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   // ---- weights: linear LDS-DMA copy (28 pieces of 1 KiB; wave w moves pieces w, w+4, ...)
   for (int i = wave; i < W_BYTES / 1024; i += 4) GLDS16((const char*)p.w + i * 1024 + lane * 16, Ws + i * 1024);
 
-  // ---- input window: convert from the caller's layout, zero outside the image.  All loads of a
-  // thread are issued before the first conversion (7 x 3 independent loads in flight) -- a
-  // load->convert->store loop exposes the HBM latency once per iteration.
-  {
-    constexpr int NI = (PR * PC + 255) / 256;                 // 7
-    float v0[NI], v1[NI], v2[NI];
+  // ---- input window: convert from the caller's layout, zero outside the image.  Thread t < 252 owns window column
+  // t % 42 and rows t / 42 + 6k (k = 0..6): one divide per thread, the column test / clamp once, and the LDS slot of
+  // item k is simply t + 252 k.  All loads of a thread are issued before the first conversion (7 x 3 independent
+  // loads in flight) -- a load->convert->store loop exposes the HBM latency once per iteration.  Vector-ALU work
+  // here is paid in MFMA issue time (they share the SIMD's issue slots), hence the care.
+  if (tid < 6 * PC) {
+    constexpr int NI = 7;
+    const int r0 = tid / PC, c = tid - r0 * PC;
+    const int x = px0 + c;
+    const bool okx = x >= 0 && x < p.W;
+    const int estep = p.in_format == 0 ? 1 : 3;
+    const int xoffs = min(max(x, 0), p.W - 1) * estep;
     int off[NI];                                              // element offset inside this image (< 2^31)
     bool ok[NI];
-    const int estep = p.in_format == 0 ? 1 : 3;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const int i = tid + k * 256;
-      const int r = i / PC, c = i - r * PC;
-      const int y = py0 + r, x = px0 + c;
-      ok[k] = i < PR * PC && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);   // always a legal address
-      off[k] = (yc * p.W + xc) * estep;
+      const int r = r0 + 6 * k, y = py0 + r;
+      ok[k] = okx && r < PR && y >= 0 && y < p.H;
+      off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;  // always a legal address
     }
     const size_t img_elems = (size_t)3 * p.H * p.W;
+    u32x2 px[NI];                                             // the 8-byte LDS pixels: c0 c1 | c2 0
 #if defined(FLOPE_STEM_ABL) && (FLOPE_STEM_ABL & 1)      // timing experiments only
-    for (int k = 0; k < NI; ++k) { v0[k] = v1[k] = v2[k] = 0.5f; }
+    for (int k = 0; k < NI; ++k) px[k] = pack4<T>(0.5f, 0.5f, 0.5f);
     if (false) {
 #else
     if (p.in_format == 0) {
 #endif
       const float* s = (const float*)p.x + (size_t)img * img_elems;
       const int plane = p.H * p.W;
+      float v0[NI], v1[NI], v2[NI];
 #pragma unroll
       for (int k = 0; k < NI; ++k) { v0[k] = s[off[k]]; v1[k] = s[off[k] + plane]; v2[k] = s[off[k] + 2 * plane]; }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) px[k] = pack4<T>(v0[k], v1[k], v2[k]);
     } else if (p.in_format == 3) {
       const unsigned char* s = (const unsigned char*)p.x + (size_t)img * img_elems;
-      unsigned char a[NI], b[NI], c[NI];
+      unsigned char a[NI], b[NI], cc[NI];
 #pragma unroll
-      for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; c[k] = s[off[k] + 2]; }
+      for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; cc[k] = s[off[k] + 2]; }
 #pragma unroll
-      for (int k = 0; k < NI; ++k) { v0[k] = (float)a[k] / 255.0f; v1[k] = (float)b[k] / 255.0f; v2[k] = (float)c[k] / 255.0f; }
+      for (int k = 0; k < NI; ++k) px[k] = pack4<T>((float)a[k] / 255.0f, (float)b[k] / 255.0f, (float)cc[k] / 255.0f);
     } else {
       const unsigned short* s = (const unsigned short*)p.x + (size_t)img * img_elems;
-      unsigned short a[NI], b[NI], c[NI];
+      unsigned short a[NI], b[NI], cc[NI];
 #pragma unroll
-      for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; c[k] = s[off[k] + 2]; }
-      if (p.in_format == 1) {
+      for (int k = 0; k < NI; ++k) { a[k] = s[off[k]]; b[k] = s[off[k] + 1]; cc[k] = s[off[k] + 2]; }
+      const bool same = (p.in_format == 1) == (sizeof(T) == 2 && std::is_same<T, bf16_t>::value);
+      if (same) {                                             // input dtype == trunk dtype: the bits pass through
 #pragma unroll
-        for (int k = 0; k < NI; ++k) {
-          v0[k] = to_f32(__builtin_bit_cast(bf16_t, a[k])); v1[k] = to_f32(__builtin_bit_cast(bf16_t, b[k]));
-          v2[k] = to_f32(__builtin_bit_cast(bf16_t, c[k]));
-        }
+        for (int k = 0; k < NI; ++k) px[k] = u32x2{(unsigned)a[k] | ((unsigned)b[k] << 16), (unsigned)cc[k]};
+      } else if (p.in_format == 1) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+          px[k] = pack4<T>(to_f32(__builtin_bit_cast(bf16_t, a[k])), to_f32(__builtin_bit_cast(bf16_t, b[k])),
+                           to_f32(__builtin_bit_cast(bf16_t, cc[k])));
       } else {
 #pragma unroll
-        for (int k = 0; k < NI; ++k) {
-          v0[k] = to_f32(__builtin_bit_cast(f16_t, a[k])); v1[k] = to_f32(__builtin_bit_cast(f16_t, b[k]));
-          v2[k] = to_f32(__builtin_bit_cast(f16_t, c[k]));
-        }
+        for (int k = 0; k < NI; ++k)
+          px[k] = pack4<T>(to_f32(__builtin_bit_cast(f16_t, a[k])), to_f32(__builtin_bit_cast(f16_t, b[k])),
+                           to_f32(__builtin_bit_cast(f16_t, cc[k])));
       }
     }
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int i = tid + k * 256;
-      if (i < PR * PC) *(u32x2*)(Ps + i * 8) = ok[k] ? pack4<T>(v0[k], v1[k], v2[k]) : u32x2{0u, 0u};
-    }
+    for (int k = 0; k < NI; ++k)
+      if (r0 + 6 * k < PR) *(u32x2*)(Ps + (tid + 6 * PC * k) * 8) = ok[k] ? px[k] : u32x2{0u, 0u};
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
