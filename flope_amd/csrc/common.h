@@ -33,11 +33,13 @@ template <typename T> __device__ __forceinline__ float to_f32(T v) { return (flo
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
 // pack two floats into one 32-bit word of two T (low half = a)
+// (a 2-vector conversion compiles to ONE v_cvt_pk_{f16,bf16}_f32 on gfx950, round-to-nearest-even like the scalar
+// cast; two scalar casts cost two converts and a v_perm -- and every vector instruction is paid in MFMA issue time)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) {
-  T x = from_f32<T>(a), y = from_f32<T>(b);
-  unsigned short ux = __builtin_bit_cast(unsigned short, x);
-  unsigned short uy = __builtin_bit_cast(unsigned short, y);
-  return (unsigned)ux | ((unsigned)uy << 16);
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  const f32x2_t f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, t2));
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(unsigned w) {
   return to_f32<T>(__builtin_bit_cast(T, (unsigned short)(w & 0xffffu)));
