@@ -218,21 +218,25 @@ __global__ __launch_bounds__(256) void depth_valid_kernel(const DT* depth, const
   }
 }
 
-// one block per box: masked mean of depth over eroded-valid pixels
+// Masked mean of depth over eroded-valid pixels.  A box is cut into kDepthStrips horizontal strips, one workgroup
+// each (one workgroup per box kept 16 CUs busy for 1.9 ms on a 1080p frame with 16 flowers); the strip partials
+// (double sum, count) are combined in strip order by depth_box_final_kernel, so the result does not depend on timing.
+constexpr int kDepthStrips = 32;
+struct DepthPartial { double sum; int cnt; int pad; };
+
 template <typename DT>
 __global__ __launch_bounds__(256) void depth_box_kernel(const DT* depth, const unsigned char* valid,
-                                                        int FH, int FW, float div, const int* boxes, float fx, float fy,
-                                                        float cx, float cy, float* depth_val, int* reliable,
-                                                        float* xyz) {
-  const int b = blockIdx.x;
+                                                        int FH, int FW, float div, const int* boxes, DepthPartial* part) {
+  const int b = blockIdx.x, strip = blockIdx.y;
   const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
   // numpy slicing semantics of depth[hmin:hmax, wmin:wmax] for in-frame, non-negative boxes
   const int xs = max(x0, 0), ys = max(y0, 0), xe = min(x1, FW), ye = min(y1, FH);
   const int bw = max(xe - xs, 0), bh = max(ye - ys, 0);
+  const int r0 = (int)((long)bh * strip / kDepthStrips), r1 = (int)((long)bh * (strip + 1) / kDepthStrips);
   double sum = 0.0;
   int cnt = 0;
-  for (int i = threadIdx.x; i < bw * bh; i += 256) {
-    const int x = xs + i % bw, y = ys + i / bw;
+  for (int i = threadIdx.x; i < bw * (r1 - r0); i += 256) {
+    const int x = xs + i % bw, y = ys + r0 + i / bw;
     bool ok = true;
     for (int ey = 0; ey < 10 && ok; ++ey) {
       const int yy = y + ey - 5;
@@ -257,17 +261,25 @@ __global__ __launch_bounds__(256) void depth_box_kernel(const DT* depth, const u
     if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const int c = scnt[0];
-    const double dv = c > 0 ? (ssum[0] / c) / 1000.0 : 0.0;
-    depth_val[b] = (float)dv;
-    reliable[b] = c >= 50 ? 1 : 0;
-    // uv = centre of the (un-squared) box; depth is the ray length (mvg.py:387-408)
-    const double u = (x0 + x1) * 0.5, v = (y0 + y1) * 0.5;
-    const double xn = (u - cx) / fx, yn = (v - cy) / fy;
-    const double z = dv / sqrt(xn * xn + yn * yn + 1.0);
-    xyz[b * 3] = (float)(xn * z); xyz[b * 3 + 1] = (float)(yn * z); xyz[b * 3 + 2] = (float)z;
-  }
+  if (threadIdx.x == 0) { part[b * kDepthStrips + strip].sum = ssum[0]; part[b * kDepthStrips + strip].cnt = scnt[0]; }
+}
+
+__global__ void depth_box_final_kernel(const DepthPartial* part, const int* boxes, int n, float fx, float fy, float cx,
+                                       float cy, float* depth_val, int* reliable, float* xyz) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  double s = 0.0;
+  int c = 0;
+  for (int k = 0; k < kDepthStrips; ++k) { s += part[b * kDepthStrips + k].sum; c += part[b * kDepthStrips + k].cnt; }
+  const double dv = c > 0 ? (s / c) / 1000.0 : 0.0;
+  depth_val[b] = (float)dv;
+  reliable[b] = c >= 50 ? 1 : 0;
+  // uv = centre of the (un-squared) box; depth is the ray length (mvg.py:387-408)
+  const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
+  const double u = (x0 + x1) * 0.5, v = (y0 + y1) * 0.5;
+  const double xn = (u - cx) / fx, yn = (v - cy) / fy;
+  const double z = dv / sqrt(xn * xn + yn * yn + 1.0);
+  xyz[b * 3] = (float)(xn * z); xyz[b * 3 + 1] = (float)(yn * z); xyz[b * 3 + 2] = (float)z;
 }
 
 extern "C" int flope_depth_lift(const void* depth_dev, int depth_format, const uint8_t* mask_dev, int frame_h,
@@ -280,20 +292,23 @@ extern "C" int flope_depth_lift(const void* depth_dev, int depth_format, const u
   const size_t npix = (size_t)frame_h * frame_w;
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+  // scratch: [H*W bytes valid mask][16-byte aligned n * kDepthStrips partial records]
+  DepthPartial* part = (DepthPartial*)(scratch_dev + ((npix + 15) & ~(size_t)15));
   if (depth_format == 0) {
     const unsigned short* d = (const unsigned short*)depth_dev;
     hipLaunchKernelGGL(depth_valid_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, d, mask_dev, npix, depth_div,
                        near_plane, far_plane, scratch_dev);
-    hipLaunchKernelGGL(depth_box_kernel<unsigned short>, dim3(n), dim3(256), 0, st, d, scratch_dev, frame_h, frame_w,
-                       depth_div, boxes_dev, K4_host[0], K4_host[1], K4_host[2], K4_host[3], depth_val_dev,
-                       reliable_dev, xyz_dev);
+    hipLaunchKernelGGL(depth_box_kernel<unsigned short>, dim3(n, kDepthStrips), dim3(256), 0, st, d, scratch_dev, frame_h,
+                       frame_w, depth_div, boxes_dev, part);
   } else {
     const float* d = (const float*)depth_dev;
     hipLaunchKernelGGL(depth_valid_kernel<float>, dim3(grid), dim3(256), 0, st, d, mask_dev, npix, depth_div,
                        near_plane, far_plane, scratch_dev);
-    hipLaunchKernelGGL(depth_box_kernel<float>, dim3(n), dim3(256), 0, st, d, scratch_dev, frame_h, frame_w, depth_div,
-                       boxes_dev, K4_host[0], K4_host[1], K4_host[2], K4_host[3], depth_val_dev, reliable_dev, xyz_dev);
+    hipLaunchKernelGGL(depth_box_kernel<float>, dim3(n, kDepthStrips), dim3(256), 0, st, d, scratch_dev, frame_h, frame_w,
+                       depth_div, boxes_dev, part);
   }
+  hipLaunchKernelGGL(depth_box_final_kernel, dim3((n + 63) / 64), dim3(64), 0, st, part, boxes_dev, n, K4_host[0], K4_host[1],
+                     K4_host[2], K4_host[3], depth_val_dev, reliable_dev, xyz_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -271,7 +271,7 @@ def depth_lift(depth_raw: torch.Tensor, mask: torch.Tensor, boxes: torch.Tensor,
     H, W = mask.shape
     boxes = boxes.to(dev, torch.int32).contiguous()
     n = boxes.shape[0]
-    scratch = torch.empty(H * W, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(H * W + 16 + 512 * n, dtype=torch.uint8, device=dev)   # valid mask + strip partials
     dv = torch.empty(n, dtype=torch.float32, device=dev)
     rel = torch.empty(n, dtype=torch.int32, device=dev)
     xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)

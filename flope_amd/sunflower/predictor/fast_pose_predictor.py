@@ -60,7 +60,10 @@ def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_s
         return None
     sq_keep = torch.from_numpy(sq_bb[keep].astype(np.int32)).to(dev)
     xyz = xyz[torch.from_numpy(keep).to(dev)]
-    crops = _engine.crop_resize_mask(frame_d, mask_d, sq_keep, crop_size, _lib.IN_F32_NCHW)
+    # crops in the trunk's own 16-bit NHWC layout when there is one: the stem would round the float32 crop to that type
+    # anyway (bit-identical result), and the crop tensor is a third of the size
+    fmt = {"f16": _lib.IN_F16_NHWC, "bf16": _lib.IN_BF16_NHWC}.get(getattr(posenet, "compute_dtype", "f32"), _lib.IN_F32_NCHW)
+    crops = _engine.crop_resize_mask(frame_d, mask_d, sq_keep, crop_size, fmt)
     _, R = posenet.predict_rotations(crops)
     Rt = _engine.compose_pose(R, xyz, nullify=True)
     return Rt.double().cpu().numpy()

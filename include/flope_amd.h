@@ -134,7 +134,8 @@ int flope_merge_masks_resize(const float* masks_dev, int n, int h, int w, uint8_
  * depth_div (1000 at fast_pose_predictor.py:90, 10000 at pose_predictor.py:118, 1 for the
  * float-metres argument of get_depth_value itself), boxes int32 [n,4]
  * (un-squared boxes), K = {fx,fy,cx,cy}.  Outputs: depth_val float32 [n] (metres),
- * reliable int32 [n], xyz float32 [n,3].  scratch_dev: >= H*W bytes. */
+ * reliable int32 [n], xyz float32 [n,3].  scratch_dev: >= H*W + 16 + 512*n bytes
+ * (valid mask, then 32 strip partials of 16 bytes per box). */
 int flope_depth_lift(const void* depth_dev, int depth_format, const uint8_t* mask_dev,
                      int frame_h, int frame_w, float depth_div, float near_plane, float far_plane,
                      const int32_t* boxes_dev, int n, const float* K4_host,
