@@ -102,6 +102,11 @@ struct ConvP {
   const void* ds_in;   // padded NHWC [B][ds_Hip][ds_Wip][ds_Cin] (the block input), nullptr = none
   const void* ds_w;    // [ntile][ds_Cin/32 half-chunks][128 rows][32 k] conv_stag image
   int ds_Hip, ds_Wip, ds_Cin;
+  // conv_stag split-K (small batches: fewer tiles than CUs): workgroup blockIdx.x handles tile blockIdx.x / ksplit and
+  // the (blockIdx.x % ksplit)-th share of the K loop, and writes raw fp32 partial sums to split_ws[ks][M][Cout];
+  // conv_split_finalize adds them up with bias / residual / ReLU.  ksplit <= 1: off.
+  int ksplit;
+  float* split_ws;
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

@@ -74,8 +74,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   const int wpx = BN == 128 ? (wl & 1) : wl, wch = BN == 128 ? (wl >> 1) : 0;
   const int g = lane >> 4, r16 = lane & 15;
   const int pcol = tile_px_s(r16);
-  const int G = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, G);
+  const int KSP = (!ROWS && p.ksplit > 1) ? p.ksplit : 1;   // split-K: KSP workgroups per tile, each a share of the K loop
+  const int ks = KSP > 1 ? (int)(blockIdx.x % KSP) : 0;
+  const int G = gridDim.x / KSP;
+  const int lb = xcd_remap(blockIdx.x / KSP, G);
   const int ntile = lb % p.ntiles;                         // constant over this workgroup's tiles
   const int HoWo = p.Ho * p.Wo;
   const int nhc = p.Cin / 32;                              // even: Cin is a multiple of 64
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     psrc0 = (unsigned)(pi * (int)pixB + js * 16);
   }
   const size_t round_stride = 128 * pixB;
-  const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + wave * 1024;   // + g*8192 for op g of a double tile
+  const int nbody = nhc / 2 / KSP, body0 = ks * nbody;      // bodies (= pairs of half-chunks = 64 input channels) of this workgroup
+  const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + (size_t)body0 * 9 * (2 * TILE_B) + wave * 1024;   // + g*8192 for op g of a double tile
   const unsigned lane16 = lane * 16;
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
   const int wbase = 2 * PATCH_B + (wch * 64 + r16) * 64 + ((g ^ wsw) << 4);
@@ -172,6 +175,12 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
+  if (KSP > 1) {                                           // partial sums: the finalize kernel adds the bias once
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // fragment reads of one double step: ring slot, patch buffers and taps are literals
 #define LOADF(slot_, buf0_, tap0_, buf1_, tap1_)   /* slot_: byte offset of the double tile's first row for this lane */                                                               \
@@ -241,8 +250,8 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       rpre[pt][1] = *(const u32x4*)(rp + 16);
     }
   }
-  // ---- prologue: patch of half-chunk 0, double tiles 0 and 1
-  ISSUE_PATCH(patch_src, 0);
+  // ---- prologue: patch of this workgroup's first half-chunk, its double tiles 0 and 1
+  ISSUE_PATCH(patch_src + (size_t)(2 * body0) * 64, 0);
   if constexpr (WRES) {
     const char* wsrc = (const char*)p.w + (size_t)ntile * NS * TILE_B + lane16;
     for (int i = wave; i < 18 * TILE_B / 1024; i += 8) GLDS16(wsrc + i * 1024, Bs + i * 1024);
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         }
   }
   BARRIER();
-  if constexpr (DSF) {
+  if constexpr (DSF) if (ks == 0) {
     static_assert(BN == 128 && !RES && !ROWS && PT >= 4, "folded downsample: 256 x 128 tiles, 32 KB patch buffers");
     // this lane's two DMA source pixels (pieces rr*512 + wave*64 + lane: pixel slot = piece >> 2, 16-byte part = piece & 3)
     const char* dsrc[2];
@@ -338,9 +347,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #endif
   u32x4 rq[(RES && ROWS) ? MT : 1][2];                      // ROWS + RES: next tile's residual, in flight from double step 6
   int dn = 2;                                               // double tile to issue at the start of the next double step
-  int hc = 0;                                               // first half-chunk of the current body
+  int hc = 2 * body0;                                       // first half-chunk of the current body
+  const int hc_end = 2 * (body0 + nbody);
   bool after_epi = false;
-  const int ND = NS / 2;                                    // double steps per tile
+  const int ND = nbody * 9;                                 // double steps per tile (of this workgroup's K share)
 #define DSTEP(D)                                                                                               \
   do {                                                                                                         \
     constexpr int U0_ = 2 * (D), U1_ = 2 * (D) + 1;                                                            \
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     ++dn;                                                                                                      \
     if ((D) == 0 && !(dbg & 2)) ISSUE_PATCH(patch_src + (hc + 1) * 64, 1);                                     \
     if ((D) == 5 && !(dbg & 2)) {                                                                              \
-      const char* s_ = hc + 2 < nhc ? patch_src + (hc + 2) * 64 : (has_next ? n_patch_src : patch_src);        \
+      const char* s_ = hc + 2 < hc_end ? patch_src + (hc + 2) * 64 : (has_next ? n_patch_src : patch_src);     \
       ISSUE_PATCH(s_, 0);                                                                                      \
     }                                                                                                          \
     if constexpr (RES && ROWS && (D) == 6) {   /* residual of the NEXT tile (of this one again at the very end) */ \
@@ -381,14 +391,24 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   } while (0)
 
   for (;;) {
-    for (int hcp = 0; hcp < nhc / 2; ++hcp) {
+    for (int hcp = 0; hcp < nbody; ++hcp) {
       DSTEP(0); DSTEP(1); DSTEP(2); DSTEP(3); DSTEP(4); DSTEP(5); DSTEP(6); DSTEP(7); DSTEP(8);
       after_epi = false;
       hc += 2;
     }
     // ---- tile finished for this wave: + bias (+ residual) (ReLU) -> 16-bit padded NHWC, straight from registers
     const bool full_tile = mend - m0 == BM;
-    {
+    if (KSP > 1) {                              // split-K: raw fp32 partial sums, [ks][flat pixel][channel]
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) {
+        const int mm = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
+        if (mm < mend) {
+          float* wp = p.split_ws + ((size_t)ks * p.M + mm) * p.Cout + cb;
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) *(f32x4*)(wp + ct * 4) = acc[pt][ct];
+        }
+      }
+    } else {
       size_t ooff[MT];
       bool ok[MT];
 #pragma unroll
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
     if constexpr (!ROWS) LANE_SETUP();          // ROWS: every tile has the first tile's address table
     dn -= ND;
-    hc = 0;
+    hc = 2 * body0;
     if (full_tile && (!res_pre || ROWS)) {
       after_epi = true;                        // the epilogue issued exactly EPI_OPS VM ops per lane
     } else {
@@ -478,6 +498,49 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #undef TILE_GEOM
 #undef XO
 #undef LANE_SETUP
+}
+
+// split-K epilogue: out = act(sum over the K shares of the fp32 partials + bias (+ residual)) -> 16-bit padded NHWC.
+// One thread = one output pixel x 8 channels (two 16-byte partial loads per share, one 16-byte store).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_split_finalize_kernel(const ConvP p) {
+  const int c8n = p.Cout >> 3;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.M * c8n) return;
+  const int m = (int)(idx / c8n), c0 = (int)(idx - (size_t)m * c8n) * 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = p.bias[c0 + i];
+  for (int ks = 0; ks < p.ksplit; ++ks) {
+    const float* wp = p.split_ws + ((size_t)ks * p.M + m) * p.Cout + c0;
+    const f32x4 a = *(const f32x4*)wp, b = *(const f32x4*)(wp + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] += a[i]; v[4 + i] += b[i]; }
+  }
+  const int HoWo = p.Ho * p.Wo;
+  const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
+  const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+  const size_t off = ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + c0) * 2;
+  if (p.res) {
+    const u32x4 rv = *(const u32x4*)((const char*)p.res + off);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q * 2] += unpack_lo<T>(rv[q]); v[q * 2 + 1] += unpack_hi<T>(rv[q]); }
+  }
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned w_ = pack2<T>(v[q * 2], v[q * 2 + 1]);
+    o[q] = p.relu ? pk_relu16(w_) : w_;
+  }
+  *(u32x4*)((char*)p.out + off) = o;
+}
+
+extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream) {
+  const size_t total = (size_t)p->M * (p->Cout >> 3);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == 0) hipLaunchKernelGGL(conv_split_finalize_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, *p);
+  else            hipLaunchKernelGGL(conv_split_finalize_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
 }
 
 template <typename T>
@@ -545,9 +608,11 @@ static void stag_rows_launch(const ConvP& p, int pt, int grid_blocks, size_t lds
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int pt = p->patch_rows_max;
+  if (p->ksplit > 1 && (p->per_image == 2 || p->res || !p->split_ws || (p->Cin / 64) % p->ksplit || p->Cout < 128 ||
+                        grid_blocks != p->total_tiles * p->ksplit)) return (int)hipErrorInvalidValue;
 #define GO(T, BN_) (p->res ? stag_launch<T, BN_, true>(*p, pt, grid_blocks, lds, st) : stag_launch<T, BN_, false>(*p, pt, grid_blocks, lds, st))
   if (p->ds_in) {                   // folded 1x1 stride-2 shortcut: one tile per workgroup, no residual input
-    if (p->Cout < 128 || p->res || pt < 4 || pt == 7 || grid_blocks != p->total_tiles || p->ds_Cin % 64 || !p->ds_w) return (int)hipErrorInvalidValue;
+    if (p->Cout < 128 || p->res || pt < 4 || pt == 7 || grid_blocks != p->total_tiles * (p->ksplit > 1 ? p->ksplit : 1) || p->ds_Cin % 64 || !p->ds_w) return (int)hipErrorInvalidValue;
     if (dtype == 0) stag_dsf_launch<bf16_t>(*p, pt, grid_blocks, lds, st); else stag_dsf_launch<f16_t>(*p, pt, grid_blocks, lds, st);
   } else if (p->per_image == 2) {          // ROWS geometry: 8-row bands of one image (p->tiles_per_image bands per image)
     if (p->Cout != 64 || p->Wo > 64 || p->Ho % 8 || (pt != 3 && pt != 5 && pt != 6 && pt != 8) || ((pt & 1) && p->Cin != 64)) return (int)hipErrorInvalidValue;

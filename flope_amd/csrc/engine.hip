@@ -31,6 +31,7 @@ extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C,
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
 extern "C" int flope_conv_stag_init();
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
+extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_stem_pool_init();
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
                                       const void* w, const float* bias, void* out, int dtype, void* stream);
@@ -87,7 +88,8 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1;   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1;
+  float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
@@ -415,6 +417,10 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
   CREATE_TRY(hipMalloc((void**)&e->feat, B * 512 * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->hidden, B * (size_t)e->bod * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&e->r9_scratch, B * 9 * sizeof(float)));
+  if (dtype != FLOPE_DT_F32) {          // split-K partials: tiles * ksplit <= num_cus, 256 x 128 fp32 per tile share
+    e->split_ws_bytes = (size_t)e->num_cus * 256 * 128 * sizeof(float);
+    CREATE_TRY(hipMalloc((void**)&e->split_ws, e->split_ws_bytes));
+  }
   for (int i = 0; i < 4; ++i) {
     CREATE_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
@@ -435,7 +441,7 @@ extern "C" int flope_destroy(flope_handle e) {
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
   for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); }
-  void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch};
+  void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
@@ -452,6 +458,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
+  else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value != 0; return prev; }
   else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
   else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
@@ -605,8 +612,23 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
                                           : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
+      // split-K for small batches: with fewer tiles than half the CUs a tile's serial K loop (up to 72 double steps)
+      // is the layer's latency; give every tile ksplit workgroups, each a share of the input channels
+      int ksp = 1;
+      if (e->opt_ksplit && c.stag == 1 && e->cur_slices == 1 && !e->opt_persist && p.total_tiles * 2 <= e->num_cus) {
+        const int bodies = c.cin / 64;
+        while (ksp * 2 <= bodies && bodies % (ksp * 2) == 0 && p.total_tiles * ksp * 2 <= e->num_cus) ksp *= 2;
+      }
+      ConvP pf;
+      if (ksp > 1) {
+        pf = p;                                    // the finalize kernel owns bias / residual / ReLU
+        p.ksplit = ksp; p.split_ws = e->split_ws; p.res = nullptr;
+        pf.ksplit = ksp; pf.split_ws = e->split_ws;
+        gridb = p.total_tiles * ksp;
+      }
       SMARK();
       K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, gridb, c.stag_lds, stream));
+      if (ksp > 1) K_TRY(e, c.name.c_str(), flope_conv_split_finalize_launch(&pf, dt, stream));
     } else {
       ConvP p; conv_params(e, vb, c, batch, &p);
       SMARK();
