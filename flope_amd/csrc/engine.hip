@@ -207,6 +207,7 @@ void plan_conv(flope_engine* e, Conv& c) {
     const long pieces = (long)rows * Wip * 4;
     int P = (int)((pieces + 511) / 512);
     if (P < 2) P = 2;                                  // kernel instantiations: 2..6 and 8 DMA rounds per patch burst
+    if (P < 4 && c.cout >= 128 && e->opt_dsfuse) P = 4;  // 32 KB buffers: room for a folded shortcut's gathered pixel tiles
     if (P == 7) P = 8;                                 // (every round is 8 KB of L2 -> LDS traffic per half-chunk and tile)
     const size_t lds = (size_t)6 * sbn * 64 + (size_t)2 * P * 8192;   // 3 double tiles + 2 patch buffers
     if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }

@@ -81,36 +81,33 @@ extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream) {
 
 // ---------------------------------------------------------------------------
 // Global average pool: padded NHWC [B][h+2][w+2][C] -> float [B][C].
-// One block per image; thread t sums channel pair (2t, 2t+1) when 16-bit.
+// One block per (image, 128 channels); thread = (pixel group pg of 4, channel pair of 64): the h*w pixels are strided
+// over the 4 groups so four independent 4-byte loads per channel pair are in flight, and the 128-channel slabs of one
+// image go to different workgroups (one workgroup per image took 41 us on 16 x 16 maps).
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_kernel(const void* in, float* out, int h, int w, int C) {
-  // one block per image; thread = (pixel group pg of 4, channel pair c2 of 64 per pass): the h*w pixels are
-  // strided over the 4 groups so four times as many independent 4-byte loads are in flight per channel
   __shared__ float red[4][128];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, c0 = blockIdx.y * 64;          // c0 in channel pairs
   const int Wp = w + 2, npx = h * w;
   const float inv = 1.f / (float)npx;
   const int pg = threadIdx.x >> 6, cl = threadIdx.x & 63;
-  for (int c0 = 0; c0 < C / 2; c0 += 64) {
-    const int c2 = c0 + cl;
-    float s0 = 0.f, s1 = 0.f;
-    if (c2 < C / 2) {
-      const unsigned* base = (const unsigned*)((const char*)in + (size_t)b * (h + 2) * Wp * C * 2) + c2;
+  const int c2 = c0 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c2 < C / 2) {
+    const unsigned* base = (const unsigned*)((const char*)in + (size_t)b * (h + 2) * Wp * C * 2) + c2;
 #pragma unroll 4
-      for (int i = pg; i < npx; i += 4) {
-        const int y = i / w, x = i - y * w;
-        const unsigned v = base[(size_t)((y + 1) * Wp + x + 1) * (C / 2)];
-        s0 += unpack_lo<T>(v);
-        s1 += unpack_hi<T>(v);
-      }
+    for (int i = pg; i < npx; i += 4) {
+      const int y = i / w, x = i - y * w;
+      const unsigned v = base[(size_t)((y + 1) * Wp + x + 1) * (C / 2)];
+      s0 += unpack_lo<T>(v);
+      s1 += unpack_hi<T>(v);
     }
-    red[pg][cl * 2] = s0; red[pg][cl * 2 + 1] = s1;
-    __syncthreads();
-    if (threadIdx.x < 128 && c0 * 2 + (int)threadIdx.x < C) {
-      const int t = threadIdx.x;
-      out[(size_t)b * C + c0 * 2 + t] = (red[0][t] + red[1][t] + red[2][t] + red[3][t]) * inv;
-    }
-    __syncthreads();
+  }
+  red[pg][cl * 2] = s0; red[pg][cl * 2 + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < 128 && c0 * 2 + (int)threadIdx.x < C) {
+    const int t = threadIdx.x;
+    out[(size_t)b * C + c0 * 2 + t] = (red[0][t] + red[1][t] + red[2][t] + red[3][t]) * inv;
   }
 }
 
@@ -128,8 +125,9 @@ __global__ __launch_bounds__(256) void avgpool_f32_kernel(const float* in, float
 
 extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, int w, int C, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(B), dim3(256), 0, st, in, out, h, w, C);
-  else if (dtype == 1) hipLaunchKernelGGL(avgpool_kernel<f16_t>, dim3(B), dim3(256), 0, st, in, out, h, w, C);
+  const dim3 grid(B, (C / 2 + 63) / 64);
+  if (dtype == 0) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, in, out, h, w, C);
+  else if (dtype == 1) hipLaunchKernelGGL(avgpool_kernel<f16_t>, grid, dim3(256), 0, st, in, out, h, w, C);
   else hipLaunchKernelGGL(avgpool_f32_kernel, dim3(B), dim3(256), 0, st, (const float*)in, out, h, w, C);
   return (int)hipGetLastError();
 }
