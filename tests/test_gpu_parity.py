@@ -263,7 +263,7 @@ def test_crop_resize_mask_vs_oracle():
     from flope_amd import engine as E
     rgb, mask, _, boxes = _scene(20)
     _, sq, _ = P.select_boxes(boxes, rgb.shape)
-    for S in (64, 512):
+    for S in (64, 512, 100, 24):         # 100: ragged 16 x 16 output tiles; 24: > 3.5x down-scaling (direct-sum path)
         sel = sq[:3] if S == 512 else sq
         got = E.crop_resize_mask(torch.from_numpy(rgb).cuda(), torch.from_numpy(mask).cuda(),
                                  torch.from_numpy(sel.astype(np.int32)).cuda(), S).cpu().numpy()
