@@ -254,45 +254,58 @@ extern "C" int flope_crop_resize_mask(const uint8_t* frame_dev, const uint8_t* m
 __constant__ signed char kEllipseLo[10] = {5, 2, 1, 0, 0, 0, 0, 0, 1, 2};
 __constant__ signed char kEllipseHi[10] = {5, 8, 9, 9, 9, 9, 9, 9, 9, 8};
 
-template <typename DT>
-__global__ __launch_bounds__(256) void depth_valid_kernel(const DT* depth, const unsigned char* mask,
-                                                          size_t npix, float div, float nearp, float farp,
-                                                          unsigned char* valid) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
-    const float d = (float)depth[i] / div;
-    valid[i] = (d > nearp && d < farp && mask[i] > 128) ? 1 : 0;
-  }
-}
-
 // Masked mean of depth over eroded-valid pixels.  A box is cut into kDepthStrips horizontal strips, one workgroup
 // each (one workgroup per box kept 16 CUs busy for 1.9 ms on a 1080p frame with 16 flowers); the strip partials
 // (double sum, count) are combined in strip order by depth_box_final_kernel, so the result does not depend on timing.
 constexpr int kDepthStrips = 32;
 struct DepthPartial { double sum; int cnt; int pad; };
 
+// valid = (near < d < far) & (mask > 128) straight from the inputs (out-of-frame = "valid": erode's default border)
 template <typename DT>
-__global__ __launch_bounds__(256) void depth_box_kernel(const DT* depth, const unsigned char* valid,
-                                                        int FH, int FW, float div, const int* boxes, DepthPartial* part) {
+__device__ __forceinline__ unsigned char depth_is_valid(const DT* depth, const unsigned char* mask, int FH, int FW, int y,
+                                                        int x, float div, float nearp, float farp) {
+  if (y < 0 || y >= FH || x < 0 || x >= FW) return 1;
+  const size_t i = (size_t)y * FW + x;
+  const float d = (float)depth[i] / div;
+  return (d > nearp && d < farp && mask[i] > 128) ? 1 : 0;
+}
+
+constexpr int kDepthLds = 48 * 1024;            // validity tile of one strip (+5 halo) when it fits
+
+template <typename DT>
+__global__ __launch_bounds__(256) void depth_box_kernel(const DT* depth, const unsigned char* mask, int FH, int FW,
+                                                        float div, float nearp, float farp, const int* boxes,
+                                                        DepthPartial* part) {
+  __shared__ unsigned char vt[kDepthLds];
   const int b = blockIdx.x, strip = blockIdx.y;
   const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
   // numpy slicing semantics of depth[hmin:hmax, wmin:wmax] for in-frame, non-negative boxes
   const int xs = max(x0, 0), ys = max(y0, 0), xe = min(x1, FW), ye = min(y1, FH);
   const int bw = max(xe - xs, 0), bh = max(ye - ys, 0);
   const int r0 = (int)((long)bh * strip / kDepthStrips), r1 = (int)((long)bh * (strip + 1) / kDepthStrips);
+  const int nr = r1 - r0;
+  // validity of the strip and its 10 x 10 neighbourhood: rows ys+r0-5 .. ys+r1+3, columns xs-5 .. xe+3
+  const int tw = bw + 9, th = nr + 9;
+  const bool tiled = nr > 0 && bw > 0 && (long)tw * th <= kDepthLds;
+  if (tiled) {
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+      const int ty = i / tw, tx = i - ty * tw;
+      vt[i] = depth_is_valid(depth, mask, FH, FW, ys + r0 - 5 + ty, xs - 5 + tx, div, nearp, farp);
+    }
+  }
+  __syncthreads();
   double sum = 0.0;
   int cnt = 0;
-  for (int i = threadIdx.x; i < bw * (r1 - r0); i += 256) {
-    const int x = xs + i % bw, y = ys + r0 + i / bw;
+  for (int i = threadIdx.x; i < bw * nr; i += 256) {
+    const int px = i % bw, py = i / bw;
+    const int x = xs + px, y = ys + r0 + py;
     bool ok = true;
-    for (int ey = 0; ey < 10 && ok; ++ey) {
-      const int yy = y + ey - 5;
-      if (yy < 0 || yy >= FH) continue;
+    for (int ey = 0; ey < 10 && ok; ++ey)
       for (int ex = kEllipseLo[ey]; ex <= kEllipseHi[ey]; ++ex) {
-        const int xx = x + ex - 5;
-        if (xx < 0 || xx >= FW) continue;
-        if (!valid[(size_t)yy * FW + xx]) { ok = false; break; }
+        const unsigned char v = tiled ? vt[(py + ey) * tw + px + ex]
+                                      : depth_is_valid(depth, mask, FH, FW, y + ey - 5, x + ex - 5, div, nearp, farp);
+        if (!v) { ok = false; break; }
       }
-    }
     if (ok) {
       const float dm = (float)depth[(size_t)y * FW + x] / div;   // metres, float32 like the reference
       sum += (double)(dm * 1000.0f);                              // reference averages millimetres
@@ -337,22 +350,14 @@ extern "C" int flope_depth_lift(const void* depth_dev, int depth_format, const u
   if (!depth_dev || !mask_dev || !boxes_dev || !scratch_dev || !depth_val_dev || !reliable_dev || !xyz_dev) return -1;
   const size_t npix = (size_t)frame_h * frame_w;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
-  // scratch: [H*W bytes valid mask][16-byte aligned n * kDepthStrips partial records]
+  // scratch: [H*W bytes, unused since the validity map became an LDS tile][16-byte aligned n * kDepthStrips partials]
   DepthPartial* part = (DepthPartial*)(scratch_dev + ((npix + 15) & ~(size_t)15));
-  if (depth_format == 0) {
-    const unsigned short* d = (const unsigned short*)depth_dev;
-    hipLaunchKernelGGL(depth_valid_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, d, mask_dev, npix, depth_div,
-                       near_plane, far_plane, scratch_dev);
-    hipLaunchKernelGGL(depth_box_kernel<unsigned short>, dim3(n, kDepthStrips), dim3(256), 0, st, d, scratch_dev, frame_h,
-                       frame_w, depth_div, boxes_dev, part);
-  } else {
-    const float* d = (const float*)depth_dev;
-    hipLaunchKernelGGL(depth_valid_kernel<float>, dim3(grid), dim3(256), 0, st, d, mask_dev, npix, depth_div,
-                       near_plane, far_plane, scratch_dev);
-    hipLaunchKernelGGL(depth_box_kernel<float>, dim3(n, kDepthStrips), dim3(256), 0, st, d, scratch_dev, frame_h, frame_w,
-                       depth_div, boxes_dev, part);
-  }
+  if (depth_format == 0)
+    hipLaunchKernelGGL(depth_box_kernel<unsigned short>, dim3(n, kDepthStrips), dim3(256), 0, st, (const unsigned short*)depth_dev,
+                       mask_dev, frame_h, frame_w, depth_div, near_plane, far_plane, boxes_dev, part);
+  else
+    hipLaunchKernelGGL(depth_box_kernel<float>, dim3(n, kDepthStrips), dim3(256), 0, st, (const float*)depth_dev, mask_dev,
+                       frame_h, frame_w, depth_div, near_plane, far_plane, boxes_dev, part);
   hipLaunchKernelGGL(depth_box_final_kernel, dim3((n + 63) / 64), dim3(64), 0, st, part, boxes_dev, n, K4_host[0], K4_host[1],
                      K4_host[2], K4_host[3], depth_val_dev, reliable_dev, xyz_dev);
   return hipGetLastError() == hipSuccess ? 0 : -2;

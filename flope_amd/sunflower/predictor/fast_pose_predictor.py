@@ -55,18 +55,21 @@ def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_s
     K4 = (K[0][0], K[1][1], K[0][2], K[1][2])
     _, reliable, xyz = _engine.depth_lift(depth_d, mask_d, torch.from_numpy(good_bb.astype(np.int32)), K4,
                                           depth_div, near, far)
-    keep = reliable.cpu().numpy()
-    if not keep.any():
-        return None
-    sq_keep = torch.from_numpy(sq_bb[keep].astype(np.int32)).to(dev)
-    xyz = xyz[torch.from_numpy(keep).to(dev)]
+    # Every in-frame box goes through the network and the unreliable ones are dropped at the very end: one device ->
+    # host round trip per frame instead of two (the reference filters first; crops are independent, so the surviving rows are
+    # the same poses up to fp32 summation order).
+    sq_all = torch.from_numpy(sq_bb.astype(np.int32)).to(dev)
     # crops in the trunk's own 16-bit NHWC layout when there is one: the stem would round the float32 crop to that type
     # anyway (bit-identical result), and the crop tensor is a third of the size
     fmt = {"f16": _lib.IN_F16_NHWC, "bf16": _lib.IN_BF16_NHWC}.get(getattr(posenet, "compute_dtype", "f32"), _lib.IN_F32_NCHW)
-    crops = _engine.crop_resize_mask(frame_d, mask_d, sq_keep, crop_size, fmt)
+    crops = _engine.crop_resize_mask(frame_d, mask_d, sq_all, crop_size, fmt)
     _, R = posenet.predict_rotations(crops)
     Rt = _engine.compose_pose(R, xyz, nullify=True)
-    return Rt.double().cpu().numpy()
+    packed = torch.cat([Rt.reshape(-1, 16), reliable.to(torch.float32).reshape(-1, 1)], dim=1).cpu().numpy()
+    keep = packed[:, 16] > 0.5
+    if not keep.any():
+        return None
+    return packed[keep, :16].reshape(-1, 4, 4).astype(np.float64)
 
 
 class FastPosePredictor:
