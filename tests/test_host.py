@@ -234,3 +234,14 @@ def test_facade_module_has_the_reference_key_set(state_dict):
     assert sum(p.numel() for p in m.parameters()) == 12245577
     with pytest.raises(RuntimeError, match="HIP devices only"):
         m(torch.rand(1, 3, 64, 64))
+
+
+def test_tools_and_entry_points_compile():
+    """bench.py, __graft_entry__.py and every tool byte-compile (they only run on a GPU box, so nothing else would
+    notice a syntax slip before the round-end run)."""
+    import glob
+    import py_compile
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")))
+    assert len(files) >= 10
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.path.join(ROOT, "build", "pyc_check.pyc"))
