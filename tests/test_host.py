@@ -243,5 +243,7 @@ def test_tools_and_entry_points_compile():
     import py_compile
     files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")))
     assert len(files) >= 10
-    for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.path.join(ROOT, "build", "pyc_check.pyc"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in files:
+            py_compile.compile(f, doraise=True, cfile=os.path.join(tmp, "check.pyc"))
