@@ -500,6 +500,155 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #undef LANE_SETUP
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv_gstag: the same 8-wave / two-staggered-groups / 256 px x 128 ch structure for the three 3x3 STRIDE-2 convs.
+// A stride-2 window has no patch reuse worth its LDS (the input region of a tile is 4x its output), so each
+// (64-channel chunk, tap) double step gets its own gathered pixel tile: 256 pixels x 64 channels = 32 KB by LDS-DMA,
+// per-lane source = that lane's input pixel (2ho + ky, 2wo + kx) in the padded tensor, full 128-byte pixel rows (a first
+// version gathered 32-channel halves per tap -- 64-byte segments, half a cache line per request -- and lost to the
+// 4-wave kernel).  Per double step a wave issues 4 gather pieces + 2 weight pieces (the tap's tiles of the chunk's two
+// half-chunks), two double steps ahead, into 3-deep rings (96 KB pixels + 48 KB weights); every wait is the constant
+// vmcnt(6).  Against conv_mfma<128x128,gather> the weight stream per MAC halves.  Pixel tiles use conv_mfma's A-tile
+// image: 128-byte rows, 16-byte slot j of row r holds chunk j ^ ((r >> 1) & 7).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_gstag_kernel(const ConvP p) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int BM = 256, GP = 128, TILE_B = 8192, DT_B = 16384, MT = 4, NT = 4;
+  constexpr int XD_B = 32768, X_BYTES = 3 * XD_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;                                   // 3 gathered pixel tiles [256 px][128 B]
+  char* const Bs = smem + X_BYTES;                         // 3 double tiles of weights
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = wave >> 2, wl = wave & 3, wpx = wl & 1, wch = wl >> 1;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int pcol = tile_px_s(r16);
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = lb % p.ntiles;
+  const int HoWo = p.Ho * p.Wo;
+  const int nchunks = p.Cin / 64, ND = nchunks * 9;        // one double step = one tap x one 64-channel chunk
+  const size_t pixB = (size_t)p.Cin * 2;
+  const int m0 = (lb / p.ntiles) * BM, mend = min(m0 + BM, p.M);
+
+  // this lane's four gather pieces per pixel tile: piece rr*512 + wave*64 + lane -> pixel row (>> 3), 16-byte slot (& 7)
+  const char* gsrc[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int q = rr * 512 + wave * 64 + lane, row = q >> 3;
+    const int m = min(m0 + row, mend - 1);
+    const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
+    const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+    gsrc[rr] = (const char*)p.in + (((size_t)b_ * p.Hip + 2 * ho_) * p.Wip + 2 * wo_) * pixB + (((q & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  int xds[MT];                                             // fragment offset of half-chunk 0; half-chunk 1 is slot ^ 4
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    const int row = group * GP + wpx * 64 + pt * 16 + pcol;
+    xds[pt] = row * 128 + ((g ^ ((row >> 1) & 7)) << 4);
+  }
+  int toff[9];                                             // byte offset of tap (ky, kx) from the window's top-left pixel
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = (int)(((t / 3) * p.Wip + (t % 3)) * (int)pixB);
+  const char* const b_base = (const char*)p.w + (size_t)ntile * (nchunks * 18) * TILE_B + wave * 1024;
+  const unsigned lane16 = lane * 16;
+  const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
+  const int wbase = X_BYTES + (wch * 64 + r16) * 64 + ((g ^ wsw) << 4);
+  const int cb = ntile * 128 + wch * 64 + g * 16;
+  float bias[NT * 4];
+#pragma unroll
+  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
+  frag wf[2][NT], xf[2][MT];
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
+
+#define G_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define G_BARRIER()                                                                                            \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    asm volatile("" ::: "memory");                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    asm volatile("" ::: "memory");                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+  // double step (chunk c_, tap t_): the gathered [256][64 ch] pixel tile and the tap's weight tiles of half-chunks 2c, 2c+1
+#define G_ISSUE(c_, t_, slot_)                                                                                 \
+  do {                                                                                                         \
+    const int o_ = toff[t_] + (c_) * 128;                                                                      \
+    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                           \
+      GLDS16(gsrc[rr] + o_, Xs + (slot_) * XD_B + (rr * 512 + wave * 64) * 16);                                \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                              \
+      GLDS16(b_base + (size_t)((2 * (c_) + h) * 9 + (t_)) * TILE_B + lane16, Bs + (slot_) * DT_B + h * TILE_B + wave * 1024); \
+  } while (0)
+
+  int ch = 0;                                              // current 64-channel chunk
+  G_ISSUE(0, 0, 0);
+  G_ISSUE(0, 1, 1);
+  G_WAIT(6);                                   // double step 0's pixels and weights landed (step 1's may fly)
+  G_BARRIER();
+  if (group == 1) G_BARRIER();                 // group B runs one phase behind group A
+
+#define G_DSTEP(D)                                                                                             \
+  do {                                                                                                         \
+    {   /* two double steps ahead: tap D + 2 of this chunk, or tap D - 7 of the next (past the end: chunk 0 again) */ \
+      const int cn_ = ch + 1 < nchunks ? ch + 1 : 0;                                                           \
+      if ((D) + 2 < 9) G_ISSUE(ch, (D) + 2, ((D) + 2) % 3); else G_ISSUE(cn_, (D) + 2 - 9, ((D) + 2) % 3);     \
+    }                                                                                                          \
+    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) {                                                        \
+      wf[0][ct] = *(const frag*)(smem + wbase + ((D) % 3) * DT_B + ct * 1024);                                 \
+      wf[1][ct] = *(const frag*)(smem + wbase + ((D) % 3) * DT_B + TILE_B + ct * 1024);                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
+      xf[0][pt] = *(const frag*)(smem + ((D) % 3) * XD_B + xds[pt]);                                           \
+      xf[1][pt] = *(const frag*)(smem + ((D) % 3) * XD_B + (xds[pt] ^ 64));                                    \
+    }                                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    G_WAIT(6);                                                                                                 \
+    G_BARRIER();                                                                                               \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                              \
+      _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                        \
+        _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                      \
+          acc[pt][ct] = Elem<T>::mfma(wf[h][ct], xf[h][pt], acc[pt][ct]);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    G_BARRIER();                                                                                               \
+  } while (0)
+
+  for (; ch < nchunks; ++ch) {
+    G_DSTEP(0); G_DSTEP(1); G_DSTEP(2); G_DSTEP(3); G_DSTEP(4); G_DSTEP(5); G_DSTEP(6); G_DSTEP(7); G_DSTEP(8);
+  }
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    const int m = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
+    conv_epilogue_px<T, NT, false>(p, acc[pt], m, m < mend, cb, bias, HoWo);
+  }
+  if (group == 0) G_BARRIER();                 // every wave executes the same number of barriers
+  G_WAIT(0);                                   // drain the wrapped-around tail DMAs before LDS is released
+#undef G_DSTEP
+#undef G_ISSUE
+#undef G_BARRIER
+#undef G_WAIT
+  (void)ND;
+}
+
+extern "C" int flope_conv_gstag_init() {
+  hipError_t e = hipFuncSetAttribute((const void*)conv_gstag_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gstag_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return (int)e;
+}
+
+// 3x3 stride-2 pad-1 convolution, Cin % 64 == 0, Cout % 128 == 0; p->mtiles = ceil(M / 256), p->ntiles = Cout / 128;
+// p->w = the conv_stag weight image ([ntile][hc*9 + tap][128 rows][32 k])
+extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream) {
+  if (p->stride != 2 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || p->res) return (int)hipErrorInvalidValue;
+  const dim3 grid(p->mtiles * p->ntiles), block(512);
+  const size_t lds = 3 * 32768 + 3 * 16384;
+  if (dtype == 0) hipLaunchKernelGGL(conv_gstag_kernel<bf16_t>, grid, block, lds, (hipStream_t)stream, *p);
+  else            hipLaunchKernelGGL(conv_gstag_kernel<f16_t>, grid, block, lds, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
 // split-K epilogue: out = act(sum over the K shares of the fp32 partials + bias (+ residual)) -> 16-bit padded NHWC.
 // One thread = one output pixel x 8 channels (two 16-byte partial loads per share, one 16-byte store).
 template <typename T>

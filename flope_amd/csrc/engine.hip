@@ -30,6 +30,8 @@ extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int 
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
 extern "C" int flope_conv_stag_init();
+extern "C" int flope_conv_gstag_init();
+extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_stem_pool_init();
@@ -88,7 +90,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_gstag = 1;
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -220,6 +222,8 @@ void plan_conv(flope_engine* e, Conv& c) {
       if (Pr <= 8 && ldsr <= kLdsMax) { c.stag = 2; c.stag_patch_bytes = Pr; c.stag_lds = ldsr; }
     }
   }
+  // 3x3 stride-2 convs: the gathered-tile variant of the same 8-wave structure (conv_gstag)
+  if (e->opt_stag && e->opt_gstag && c.k == 3 && c.stride == 2 && c.cin % 64 == 0 && c.cin >= (e->opt_gstag >= 2 ? 64 : 128) && c.cout % 128 == 0) c.stag = 3;   // gstag: 1 = Cin >= 128 (K = 576 is too short to amortise the 8-wave prologue), 2 = every stride-2 3x3
 }
 
 void conv_params(const flope_engine* e, const std::vector<Buf>& bufs, const Conv& c, int batch, ConvP* p) {
@@ -351,6 +355,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     if (s == 0) s = flope_stem_init();
     if (s == 0) s = flope_stem_pool_init();
     if (s == 0) s = flope_conv_stag_init();
+    if (s == 0) s = flope_conv_gstag_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
   const size_t B = (size_t)max_batch;
@@ -460,6 +465,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value != 0; return prev; }
+  else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
   else if (!strcmp(name, "streams")) { prev = e->opt_streams; e->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); return prev; }
@@ -501,7 +507,7 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
     if (e->dtype == FLOPE_DT_F32) { if ((rc = upload(e, naive_layout(wf, c.cout, c.cin, c.k), (void**)&c.w_naive)) != 0) return rc; }
     else {
       if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc;
-      if (c.k == 3 && c.stride == 1 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
+      if (c.k == 3 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
       if (c.k == 1 && c.cout >= 128 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32_1x1(wf, c.cout, c.cin, e->dtype), &c.w_ds_stag)) != 0) return rc;
     }
     host_bias.push_back(bf);
@@ -592,6 +598,11 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       p.in_off = c.k == 3 ? 0 : 1; p.relu = c.relu;
       SMARK();
       K_TRY(e, c.name.c_str(), flope_naive_conv_launch(&p, stream));
+    } else if (c.stag == 3) {
+      ConvP p; conv_params(e, vb, c, batch, &p);
+      p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + 255) / 256; p.ntiles = c.cout / 128; p.total_tiles = p.mtiles * p.ntiles;
+      SMARK();
+      K_TRY(e, c.name.c_str(), flope_conv_gstag_launch(&p, dt, stream));
     } else if (c.stag) {
       ConvP p; conv_params(e, vb, c, batch, &p);
       const int sbm = c.cout == 64 ? 512 : 256;
@@ -792,6 +803,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     int BM, BN; tile_dims(c.cfg, &BM, &BN);
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
+    else if (c.stag == 3) snprintf(k, sizeof k, "conv_gstag_kernel<256x128,s2>");
     else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
@@ -817,6 +829,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
   snprintf(line, sizeof line, "stem: tiles/img=%d rows=%d lds=%zu\n", e->stem_tiles, e->stem_rows, e->stem_lds);
   s += line;
   for (const Conv& c : e->convs) {
+    if (c.stag == 3) { snprintf(line, sizeof line, "%s: 3x3 s2 %d->%d out %dx%d conv_gstag 256x128 (gathered tiles) lds=147456\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
