@@ -31,8 +31,18 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(crop: int, budget_s: float = 15.0):
-    """Oracle forward + Procrustes on the host cores, B = 16."""
+def source_digest() -> str:
+    """sha256 over the kernel sources the library is built from: ties a committed PMC traffic figure to a build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "flope_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(crop: int, batch: int = 16, budget_s: float = 12.0):
+    """Oracle forward + Procrustes on the host cores (B = 16 and B = 256)."""
     from flope_amd.weights import synthetic_state_dict
     from oracle import posenet_ref as O
     # the box's CPU share, not the host's core count: affinity mask, then the cgroup quota, and never more
@@ -49,9 +59,9 @@ def cpu_baseline(crop: int, budget_s: float = 15.0):
     torch.set_num_threads(threads)
     sd = synthetic_state_dict(0)
     torch.manual_seed(0)
-    x = torch.rand(16, 3, crop, crop)
+    x = torch.rand(batch, 3, crop, crop)
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(2 if batch <= 16 else 1):
             O.procrustes_to_rotmat(O.forward(sd, x))
         times = []
         t_end = time.perf_counter() + budget_s
@@ -61,14 +71,14 @@ def cpu_baseline(crop: int, budget_s: float = 15.0):
             times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(16 / med, 2), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} x (16 crops {crop}x{crop} fp32, torch CPU eval-mode oracle + SVD Procrustes), median"}
+    return {"value": round(batch / med, 2), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} x ({batch} crops {crop}x{crop} fp32, torch CPU eval-mode oracle + SVD Procrustes), median"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default=os.environ.get("FLOPE_DTYPE", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--crop", type=int, default=224)
@@ -96,7 +106,7 @@ def main():
     B, S, K, W = args.batch, args.crop, args.steps, args.warmup
     sd = synthetic_state_dict(0)
 
-    def build(dtype):
+    def build(dtype, S=S):
         eng = E.PoseEngine(S, S, B, dtype, device=dev)
         eng.load_state_dict(sd)
         tdt = torch.float16 if dtype == "f16" else torch.bfloat16
@@ -110,8 +120,8 @@ def main():
             # the pose buffer; R is kept too (the parity sample below reads it)
             eng.forward_poses_into(x, fmt, xyz, True, poses[i % poses.shape[0]], R)
 
-    def measure(dtype):
-        eng, x, fmt = build(dtype)
+    def measure(dtype, S=S, K=K, W=W):
+        eng, x, fmt = build(dtype, S)
         R = torch.empty(B, 9, device=dev)
         xyz = torch.zeros(B, 3, device=dev)                      # translation comes from depth (cfg3); zeros here
         poses = torch.empty(max(K, 1), B, 16, device=dev)
@@ -125,6 +135,27 @@ def main():
         dt = D.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearse else dev)
         assert allp.shape == (world * K * B, 16)
         return eng, x, fmt, dt, R, xyz, poses
+
+    def step_times_ms(eng, x, fmt, n, poses, R, xyz):
+        """Per-step GPU time: events on the launch stream around every step (the engine forks its slice streams from
+        that stream and joins them back, so the pair brackets the whole step).  A second pass, after the timed one."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            eng.forward_poses_into(x, fmt, xyz, True, poses[i % poses.shape[0]], R)
+            ev[i + 1].record()
+        torch.cuda.synchronize(dev)
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+
+    def oracle_sample_err(eng, x, fmt, R):
+        from oracle import posenet_ref as O
+        xs = x[:8].float().permute(0, 3, 1, 2).cpu()
+        Rref = O.procrustes_to_rotmat(O.forward(sd, xs))
+        eng.forward_into(x, fmt, None, R)
+        torch.cuda.synchronize(dev)
+        return {"max_abs_R": float((R[:8].view(8, 3, 3).cpu() - Rref).abs().max()),
+                "max_angle_deg": float(O.geodesic_deg(R[:8].view(8, 3, 3).cpu(), Rref).max()),
+                "sample": "8 crops of the bench batch vs fp32 CPU oracle"}
 
     eng, x, fmt, dt, R, xyz, poses = measure(args.dtype)
     value = world * K * B / dt
@@ -142,6 +173,10 @@ def main():
     }
 
     if rank == 0:
+        st = step_times_ms(eng, x, fmt, K, poses, R, xyz)
+        out["ms_per_step_median"] = round(st[len(st) // 2], 4)
+        out["ms_per_step_min"] = round(st[0], 4)
+        out["poses_per_sec_at_median_step"] = round(B / (st[len(st) // 2] * 1e-3), 1)
         # ---- roofline: per-launch HIP-event times of the same steps (profile mode) ------------------
         eng.set_option("profile", 1)
         info = eng.launch_info(B)
@@ -168,37 +203,49 @@ def main():
                            "step_frac_of_peak": round(value / world * eng.flops(1) / 1e12 / PEAK_TFLOPS, 4)}
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # figure is the committed rocprofv3 --pmc result for this same workload (profiles/r01_traffic.json)
+        # (profiles/r02_traffic.json, tied to the kernel sources by their digest: a different build => null)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(dom)
-            if tr and (B, S, args.dtype) == (256, 224, "f16"):
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tr = tj["kernels"].get(dom)
+            if tr and (B, S, args.dtype) == (256, 224, "f16") and tj.get("source_digest") == source_digest():
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+                out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
         except (OSError, ValueError, KeyError):
             pass
+        out["source_digest"] = source_digest()
         out["kernels_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
         # ---- parity of this very configuration against the oracle on a sample ---------------------
-        from oracle import posenet_ref as O
-        xs = x[:8].float().permute(0, 3, 1, 2).cpu()
-        Rref = O.procrustes_to_rotmat(O.forward(sd, xs))
-        eng.forward_into(x, fmt, None, R)
-        torch.cuda.synchronize(dev)
-        out["rot_err_vs_oracle"] = {"max_abs_R": float((R[:8].view(8, 3, 3).cpu() - Rref).abs().max()),
-                                    "max_angle_deg": float(O.geodesic_deg(R[:8].view(8, 3, 3).cpu(), Rref).max()),
-                                    "sample": "8 crops of the bench batch vs fp32 CPU oracle"}
+        out["rot_err_vs_oracle"] = oracle_sample_err(eng, x, fmt, R)
     eng.close()
 
     if not args.no_alt and world == 1:
         alt = "bf16" if args.dtype == "f16" else "f16"
-        eng2, _, _, dt2, _, _, _ = measure(alt)
-        out["alt_dtype"] = {"dtype": alt, "value": round(K * B / dt2, 1), "ms_per_step": round(dt2 / K * 1e3, 4)}
+        eng2, x2, fmt2, dt2, R2, _, _ = measure(alt)
+        err2 = oracle_sample_err(eng2, x2, fmt2, R2)
+        out["alt_dtype"] = {"dtype": alt, "value": round(K * B / dt2, 1), "ms_per_step": round(dt2 / K * 1e3, 4),
+                            "max_abs_R_vs_oracle": err2["max_abs_R"], "meets_1e-3": err2["max_abs_R"] <= 1e-3}
         eng2.close()
+        # BASELINE.json quotes configs[1] in bf16; the headline dtype is the one that meets north_star's 1e-3 gate
+        out["bf16_meets_1e-3"] = bool(out["alt_dtype"]["meets_1e-3"]) if alt == "bf16" else bool(out["rot_err_vs_oracle"]["max_abs_R"] <= 1e-3)
+        out["headline_dtype_meets_1e-3"] = bool(out["rot_err_vs_oracle"]["max_abs_R"] <= 1e-3)
+        # the reference's own crop size (fast_pose_predictor.py:115-116): 512 x 512, same batch
+        if S == 224:
+            k5 = max(5, K // 5)
+            eng5, _, _, dt5, _, _, _ = measure(args.dtype, S=512, K=k5, W=2)
+            out["alt_shapes"] = {"512": {"value": round(k5 * B / dt5, 1), "ms_per_step": round(dt5 / k5 * 1e3, 4), "steps": k5,
+                                         "step_frac_of_peak": round(k5 * B / dt5 * eng5.flops(1) / 1e12 / PEAK_TFLOPS, 4),
+                                         "note": "reference-true crop size, batch %d" % B}}
+            eng5.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(S)
+        out["cpu_baseline"] = cpu_baseline(S, 16)
+        big = cpu_baseline(S, 256, budget_s=8.0)
+        out["cpu_baseline"]["batch_256"] = {"value": big["value"], "sample": big["sample"]}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        D.barrier()                       # rank 0 profiles / checks after the timed region: nobody tears down before it is done
         torch.distributed.destroy_process_group()
 
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "flope_nullify_yaw": (_I, [_P, _P, _I, _P]),
     "flope_compose_pose": (_I, [_P, _P, _I, _I, _P, _P]),
     "flope_crop_resize_mask": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, _P, _P]),
+    "flope_lanczos4_table": (_I, [_I, _I, _P, _P, _P]),
     "flope_merge_masks_resize": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P]),
     "flope_depth_lift": (_I, [_P, _I, _P, _I, _I, _F, _F, _F, _P, _I, C.POINTER(_F), _P, _P, _P, _P, _P]),
     "flope_read_stage": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int64), _P]),

@@ -61,6 +61,17 @@ __device__ __forceinline__ unsigned pk_max16_nonneg(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
 }
 
+// 16-bit store of an epilogue pair: optional ReLU, and for float16 saturation at +-65504 -- a residual stream that
+// outgrows the float16 range would otherwise become inf here, NaN one layer later and a garbage rotation with no error
+// (bfloat16 has float32's range and needs nothing).  One v_pk_min_f16 (+ v_pk_max_f16 without ReLU) per two channels.
+template <typename T> __device__ __forceinline__ unsigned pk_out16(unsigned w, bool relu) { return relu ? pk_relu16(w) : w; }
+template <> __device__ __forceinline__ unsigned pk_out16<f16_t>(unsigned w, bool relu) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t hi = {(_Float16)65504.f, (_Float16)65504.f}, lo = {(_Float16)-65504.f, (_Float16)-65504.f};
+  if (relu) return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(h2_t, pk_relu16(w)), hi));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(h2_t, w), hi), lo));
+}
+
 // Bijective XCD-aware block remap (blocks b and b+8 share an XCD under the
 // observed round-robin dispatch; speed only, never correctness): each XCD gets a
 // contiguous run of logical tile ids so tiles that share halo rows / weight
@@ -167,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue_at(const ConvP& p, const f32x4 (&a
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned w = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
-      o[q] = p.relu ? pk_relu16(w) : w;                    // ReLU on the packed pair (sign test is rounding-invariant)
+      o[q] = pk_out16<T>(w, p.relu);                       // ReLU on the packed pair (sign test is rounding-invariant)
     }
     *(u32x4*)(op + c * 16) = o;
   }

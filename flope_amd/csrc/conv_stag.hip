@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const unsigned w_ = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
-              o[q] = p.relu ? pk_relu16(w_) : w_;            // ReLU on the packed pair: one op per two channels
+              o[q] = pk_out16<T>(w_, p.relu);                // ReLU (+ float16 saturation) on the packed pair
             }
             *(u32x4*)(op + c * 16) = o;
           }
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void conv_split_finalize_kernel(const ConvP p)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned w_ = pack2<T>(v[q * 2], v[q * 2 + 1]);
-    o[q] = p.relu ? pk_relu16(w_) : w_;
+    o[q] = pk_out16<T>(w_, p.relu);
   }
   *(u32x4*)((char*)p.out + off) = o;
 }

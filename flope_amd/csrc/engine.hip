@@ -674,6 +674,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   if (!x_dev) return fail(e, FLOPE_EINVAL, "forward: x_dev is NULL");
   if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "forward: batch must be within 1..max_batch");
   if (in_format < 0 || in_format > 3) return fail(e, FLOPE_EINVAL, "forward: unknown input format");
+  HIP_TRY(e, hipSetDevice(e->device));               // the handle's device, whatever the caller's current device is
   e->ev_n = 0;
   e->last_fused = e->opt_fuse_stem && e->dtype != FLOPE_DT_F32;
   e->last_batch = batch;
@@ -686,8 +687,10 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
   // slices are launched layer-interleaved?  No: each slice's whole sequence goes to its own stream; the
   // hardware queues interleave them, and a slice's short tail round overlaps another slice's next launch.
-  for (int s = 0; s < ns; ++s) {
-    HIP_TRY(e, hipStreamWaitEvent(e->side[s], e->ev_fork, 0));
+  int rc_all = FLOPE_OK, forked = 0;
+  for (int s = 0; s < ns && rc_all == FLOPE_OK; ++s) {
+    if (hipStreamWaitEvent(e->side[s], e->ev_fork, 0) != hipSuccess) { rc_all = fail(e, FLOPE_EHIP, "hipStreamWaitEvent(fork) failed"); break; }
+    forked = s + 1;
     // slice boundaries on multiples of 8 images (whole tiles in every layer) when the batch allows it
     auto bound = [&](int k) { const int b_ = (int)((long)batch * k / ns); return (batch >= 16 * ns && k > 0 && k < ns) ? ((b_ + 4) & ~7) : b_; };
     int start = bound(s), cnt = bound(s + 1) - start;
@@ -700,12 +703,21 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
       first = std::max(1, std::min(batch - 1, first));
       start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
     }
-    int rc = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false, head, r9_dev, R_dev, po);
-    if (rc) return rc;
-    HIP_TRY(e, hipEventRecord(e->ev_join[s], e->side[s]));
+    rc_all = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false, head, r9_dev, R_dev, po);
   }
-  for (int s = 0; s < ns; ++s) HIP_TRY(e, hipStreamWaitEvent(user, e->ev_join[s], 0));
-  return FLOPE_OK;
+  // join every stream that was forked -- also after a failed launch, so that work already queued on the side
+  // streams stays ordered before the caller's next use of x / r9 / R / Rt
+  const std::string first_err = rc_all != FLOPE_OK ? e->err : std::string();
+  for (int s = 0; s < forked; ++s)
+    if (hipEventRecord(e->ev_join[s], e->side[s]) != hipSuccess || hipStreamWaitEvent(user, e->ev_join[s], 0) != hipSuccess) {
+      hipStreamSynchronize(e->side[s]);
+      if (rc_all == FLOPE_OK) rc_all = fail(e, FLOPE_EHIP, "joining the batch-slice streams failed");
+    }
+  if (rc_all != FLOPE_OK) {
+    if (!first_err.empty()) { e->err = first_err; g_last_error = first_err; }
+    e->cur_slices = 1; e->cur_batch = 1; e->last_batch = 0;
+  }
+  return rc_all;
 }
 
 extern "C" int flope_forward(flope_handle e, const void* x_dev, int in_format, int batch, float* r9_dev, float* R_dev,
@@ -736,6 +748,7 @@ extern "C" int flope_read_stage(flope_handle e, int stage, int batch, float* dst
   if (!e) return fail(nullptr, FLOPE_EINVAL, "flope_read_stage: NULL handle");
   if (!dst_dev || !dims_out) return fail(e, FLOPE_EINVAL, "flope_read_stage: NULL argument");
   if (batch < 1 || batch > e->maxB) return fail(e, FLOPE_EINVAL, "flope_read_stage: bad batch");
+  HIP_TRY(e, hipSetDevice(e->device));
   if (stage == FLOPE_STAGE_FEAT || stage == FLOPE_STAGE_HIDDEN) {
     const int nn = stage == FLOPE_STAGE_FEAT ? 512 : e->bod;
     dims_out[0] = batch; dims_out[1] = nn; dims_out[2] = 1; dims_out[3] = 1;

@@ -100,30 +100,69 @@ extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C,
 // saturated).  Horizontal then vertical passes accumulate in int32 without intermediate
 // rounding; the result is (acc + 2^21) >> 22 saturated to uint8.  Because no rounding
 // happens between the passes a direct 8x8 sum is bit-identical to the two-pass form.  Then (fast_pose_predictor.py:118,121): out = img * (mask / 255.0) / 255.0.
+// Every floating-point step below is the one OpenCV's C++ performs (resize.cpp, interpolateLanczos4 + the 8-bit
+// coefficient quantisation), spelled with explicit round-to-nearest intrinsics so that the device compiler can neither
+// fuse a multiply-add nor re-associate: (x + 3) and (x + 3 - i) are FLOAT operations there, the angle products are
+// double, left to right.
 __device__ __forceinline__ void lanczos4_coeffs(float x, short* c16) {
   const double s45 = 0.70710678118654752440084436210485;
   const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
   const double PI = 3.1415926535897932384626433832795;
   float coeffs[8];
   float sum = 0.f;
-  const double y0 = -(x + 3) * PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+  const float xp3 = __fadd_rn(x, 3.f);
+  const double y0 = __dmul_rn(__dmul_rn(-(double)xp3, PI), 0.25), s0 = sin(y0), c0 = cos(y0);
   for (int i = 0; i < 8; ++i) {
-    const float y0_ = (x + 3 - i);
+    const float y0_ = __fsub_rn(xp3, (float)i);
     if (fabsf(y0_) >= 1e-6f) {
-      const double y = -y0_ * PI * 0.25;
-      coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+      const double y = __dmul_rn(__dmul_rn(-(double)y0_, PI), 0.25);
+      coeffs[i] = (float)__ddiv_rn(__dadd_rn(__dmul_rn(cs[i][0], s0), __dmul_rn(cs[i][1], c0)), __dmul_rn(y, y));
     } else {
       coeffs[i] = 1e30f;
     }
-    sum += coeffs[i];
+    sum = __fadd_rn(sum, coeffs[i]);
   }
-  sum = 1.f / sum;
+  sum = __fdiv_rn(1.f, sum);
   for (int i = 0; i < 8; ++i) {
-    const float v = coeffs[i] * sum * 2048.f;
+    const float v = __fmul_rn(__fmul_rn(coeffs[i], sum), 2048.f);
     int q = (int)rintf(v);                       // cvRound: round half to even
     q = q > 32767 ? 32767 : (q < -32768 ? -32768 : q);
     c16[i] = (short)q;
   }
+}
+
+// destination index d of an axis resized n_src -> n_dst: first tap position and the eight int16 weights.
+// cv::resize: inv_scale = (double)n_dst / n_src, scale = 1. / inv_scale; fx = (float)((d + 0.5) * scale - 0.5);
+// sx = cvFloor(fx); fx -= sx
+__device__ __forceinline__ int lanczos4_axis(int d, int n_src, int n_dst, short* c16) {
+  const double scale = __ddiv_rn(1.0, __ddiv_rn((double)n_dst, (double)n_src));
+  float f = (float)__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5);
+  const int s0 = (int)floorf(f);
+  f = __fsub_rn(f, (float)s0);
+  lanczos4_coeffs(f, c16);
+  return s0;
+}
+
+// test hook: the coefficient tables of one axis exactly as the crop kernel evaluates them
+__global__ void lanczos4_table_kernel(int n_src, int n_dst, int* s0_out, short* coef_out) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n_dst) return;
+  short c[8];
+  s0_out[d] = lanczos4_axis(d, n_src, n_dst, c);
+  for (int k = 0; k < 8; ++k) coef_out[d * 8 + k] = c[k];
+}
+
+extern "C" int flope_lanczos4_table(int n_src, int n_dst, int32_t* s0_dev, int16_t* coef_dev, void* stream) {
+  if (n_src < 1 || n_dst < 1 || !s0_dev || !coef_dev) return -1;
+  hipLaunchKernelGGL(lanczos4_table_kernel, dim3((n_dst + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_src, n_dst, s0_dev,
+                     coef_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// out = img * (mask / 255.0) / 255.0 in double like the reference's numpy expression (fast_pose_predictor.py:118,121),
+// rounded once to float32 by the torch conversion (:122)
+__device__ __forceinline__ float masked_unit(int img, int m) {
+  return (float)__ddiv_rn(__dmul_rn((double)img, __ddiv_rn((double)m, 255.0)), 255.0);
 }
 
 // Tiled, separable form (bit-identical to the direct 8x8 sum: sum_ky (sum_kx src*ax) * ay with exact integer partial
@@ -150,12 +189,8 @@ __global__ __launch_bounds__(256) void crop_resize_mask_tiled_kernel(const unsig
   if (live && tid < 32) {
     const bool isy = tid >= 16;
     const int d = isy ? ty * 16 + (tid - 16) : tx * 16 + tid;
-    const double sc = isy ? (double)ch / S : (double)cw / S;        // cv::resize: scale in double, coordinate in float
-    float f = (float)((d + 0.5) * sc - 0.5);
-    const int s0 = (int)floorf(f);
-    f -= s0;
     short c[8];
-    lanczos4_coeffs(f, c);
+    const int s0 = lanczos4_axis(d, isy ? ch : cw, S, c);
     for (int k = 0; k < 8; ++k) (isy ? cy[tid - 16][k] : cx[tid][k]) = c[k];
     (isy ? sys_[tid - 16] : sxs[tid]) = s0;
   }
@@ -193,8 +228,8 @@ __global__ __launch_bounds__(256) void crop_resize_mask_tiled_kernel(const unsig
         a0 += hp[0] * wv; a1 += hp[1] * wv; a2 += hp[2] * wv; am += hp[3] * wv;
       }
       auto fin = [](int v) { v = (v + (1 << 21)) >> 22; return v < 0 ? 0 : (v > 255 ? 255 : v); };
-      const float mk = (float)fin(am) / 255.0f;
-      o0 = (float)fin(a0) * mk / 255.0f; o1 = (float)fin(a1) * mk / 255.0f; o2 = (float)fin(a2) * mk / 255.0f;
+      const int mk = fin(am);
+      o0 = masked_unit(fin(a0), mk); o1 = masked_unit(fin(a1), mk); o2 = masked_unit(fin(a2), mk);
     } else {                                                        // very strong down-scaling: direct 8 x 8 sum
       int a0 = 0, a1 = 0, a2 = 0, am = 0;
       if (dx < S && dy < S) {
@@ -216,8 +251,8 @@ __global__ __launch_bounds__(256) void crop_resize_mask_tiled_kernel(const unsig
         }
       }
       auto fin = [](int v) { v = (v + (1 << 21)) >> 22; return v < 0 ? 0 : (v > 255 ? 255 : v); };
-      const float mk = (float)fin(am) / 255.0f;
-      o0 = (float)fin(a0) * mk / 255.0f; o1 = (float)fin(a1) * mk / 255.0f; o2 = (float)fin(a2) * mk / 255.0f;
+      const int mk = fin(am);
+      o0 = masked_unit(fin(a0), mk); o1 = masked_unit(fin(a1), mk); o2 = masked_unit(fin(a2), mk);
     }
   }
   if (dx >= S || dy >= S) return;
@@ -422,6 +457,6 @@ extern "C" int flope_merge_masks_resize(const float* masks_dev, int n, int h, in
   hipLaunchKernelGGL(merge_masks_kernel, dim3((h * w + 255) / 256), dim3(256), 0, st, masks_dev, n, h * w, merged);
   if (!same)
     hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, merged, h, w, out_dev, H, W,
-                       (double)w / W, (double)h / H);
+                       1.0 / ((double)W / w), 1.0 / ((double)H / h));    // cv::resize: scale = 1. / inv_scale
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

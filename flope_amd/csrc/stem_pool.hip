@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
 #pragma unroll
           for (int w2 = 0; w2 < 4; ++w2) {
             const int c = h * 8 + w2 * 2;                   // channel pair c, c+1 of this lane's 16
-            o[h][w2] = pk_relu16(pack2<T>(acc[pt][c >> 2][c & 3], acc[pt][(c + 1) >> 2][(c + 1) & 3]));
+            o[h][w2] = pk_out16<T>(pack2<T>(acc[pt][c >> 2][c & 3], acc[pt][(c + 1) >> 2][(c + 1) & 3]), true);
           }
         if (edge) {
           const int qr = q / CR, qc = q - qr * CR;

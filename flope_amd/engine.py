@@ -115,8 +115,23 @@ class PoseEngine:
         self._keep = x
         return r9, R
 
+    def _check_into(self, x: torch.Tensor, fmt: int, **outs) -> None:
+        """Host-only checks of the allocation-free entry points (no device work): device, layout, size of every
+        caller-owned buffer -- a wrong one would be a silent out-of-bounds access on the device."""
+        if self._check_input(x) != fmt:
+            raise ValueError(f"fmt {fmt} does not describe a {x.dtype} tensor of shape {tuple(x.shape)}")
+        if not x.is_contiguous():
+            raise ValueError("crop batch must be contiguous")
+        B = x.shape[0]
+        for name, (t, per) in outs.items():
+            if t is None:
+                continue
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < B * per:
+                raise ValueError(f"{name}: need a contiguous float32 buffer of >= {B * per} elements on {self.device}")
+
     def forward_into(self, x: torch.Tensor, fmt: int, r9: torch.Tensor | None, R: torch.Tensor | None) -> None:
         """Allocation-free variant for timed loops (buffers owned by the caller)."""
+        self._check_into(x, fmt, r9=(r9, 9), R=(R, 9))
         rc = self.lib.flope_forward(self.handle, x.data_ptr(), fmt, x.shape[0],
                                     r9.data_ptr() if r9 is not None else None,
                                     R.data_ptr() if R is not None else None, _stream_ptr(self.device))
@@ -125,6 +140,7 @@ class PoseEngine:
     def forward_poses_into(self, x: torch.Tensor, fmt: int, xyz: torch.Tensor | None, nullify: bool, Rt: torch.Tensor,
                            R: torch.Tensor | None = None) -> None:
         """Allocation-free: crops -> [B,16] poses (Procrustes, optional yaw-null, Rt assembly in the head kernel)."""
+        self._check_into(x, fmt, xyz=(xyz, 3), Rt=(Rt, 16), R=(R, 9))
         rc = self.lib.flope_forward_poses(self.handle, x.data_ptr(), fmt, x.shape[0],
                                           xyz.data_ptr() if xyz is not None else None, int(bool(nullify)), None,
                                           R.data_ptr() if R is not None else None, Rt.data_ptr(), _stream_ptr(self.device))
@@ -206,14 +222,16 @@ def procrustes(M: torch.Tensor) -> torch.Tensor:
     """special_procrustes on the GPU: [...,9] or [...,3,3] -> [N,3,3] (same dtype/device as M)."""
     d, src = _as_dev_f32(M, 9)
     out = torch.empty_like(d)
-    _lib.check(_lib.load().flope_procrustes(d.data_ptr(), out.data_ptr(), d.shape[0], _stream_ptr(d.device)))
+    with torch.cuda.device(d.device):
+        _lib.check(_lib.load().flope_procrustes(d.data_ptr(), out.data_ptr(), d.shape[0], _stream_ptr(d.device)))
     return out.view(-1, 3, 3).to(device=src, dtype=M.dtype if M.is_floating_point() else torch.float32)
 
 
 def nullify_yaw(R: torch.Tensor) -> torch.Tensor:
     d, src = _as_dev_f32(R, 9)
     out = torch.empty_like(d)
-    _lib.check(_lib.load().flope_nullify_yaw(d.data_ptr(), out.data_ptr(), d.shape[0], _stream_ptr(d.device)))
+    with torch.cuda.device(d.device):
+        _lib.check(_lib.load().flope_nullify_yaw(d.data_ptr(), out.data_ptr(), d.shape[0], _stream_ptr(d.device)))
     return out.view(-1, 3, 3).to(device=src, dtype=R.dtype)
 
 
@@ -221,8 +239,9 @@ def compose_pose(R: torch.Tensor, xyz: torch.Tensor | None, nullify: bool) -> to
     d, _ = _as_dev_f32(R, 9)
     x = None if xyz is None else xyz.detach().reshape(-1, 3).to(d.device, torch.float32).contiguous()
     out = torch.empty((d.shape[0], 4, 4), dtype=torch.float32, device=d.device)
-    _lib.check(_lib.load().flope_compose_pose(d.data_ptr(), x.data_ptr() if x is not None else None, d.shape[0],
-                                              int(bool(nullify)), out.data_ptr(), _stream_ptr(d.device)))
+    with torch.cuda.device(d.device):
+        _lib.check(_lib.load().flope_compose_pose(d.data_ptr(), x.data_ptr() if x is not None else None, d.shape[0],
+                                                  int(bool(nullify)), out.data_ptr(), _stream_ptr(d.device)))
     return out
 
 
@@ -239,9 +258,11 @@ def crop_resize_mask(frame: torch.Tensor, mask: torch.Tensor, boxes: torch.Tenso
     else:
         dt = torch.bfloat16 if out_format == _lib.IN_BF16_NHWC else torch.float16
         out = torch.empty((n, size, size, 3), dtype=dt, device=frame.device)
-    _lib.check(_lib.load().flope_crop_resize_mask(frame.contiguous().data_ptr(), mask.contiguous().data_ptr(), H, W,
-                                                  boxes.data_ptr(), n, size, out_format, out.data_ptr(),
-                                                  _stream_ptr(frame.device)))
+    mask = mask.to(frame.device)
+    with torch.cuda.device(frame.device):
+        _lib.check(_lib.load().flope_crop_resize_mask(frame.contiguous().data_ptr(), mask.contiguous().data_ptr(), H, W,
+                                                      boxes.data_ptr(), n, size, out_format, out.data_ptr(),
+                                                      _stream_ptr(frame.device)))
     return out
 
 
@@ -257,9 +278,22 @@ def merge_masks_resize(masks: torch.Tensor, H: int, W: int) -> torch.Tensor:
     n, h, w = m.shape
     out = torch.empty((H, W), dtype=torch.uint8, device=m.device)
     scratch = torch.empty(h * w, dtype=torch.uint8, device=m.device)
-    _lib.check(_lib.load().flope_merge_masks_resize(m.data_ptr() if n else None, n, h, w, scratch.data_ptr(), out.data_ptr(),
-                                                    H, W, _stream_ptr(m.device)))
+    with torch.cuda.device(m.device):
+        _lib.check(_lib.load().flope_merge_masks_resize(m.data_ptr() if n else None, n, h, w, scratch.data_ptr(),
+                                                        out.data_ptr(), H, W, _stream_ptr(m.device)))
     return out
+
+
+def lanczos4_table(n_src: int, n_dst: int, device="cuda"):
+    """Test hook: one axis of the crop kernel's Lanczos-4 tables -> (first tap position int32 [n_dst], int16 weights
+    [n_dst,8]), evaluated on the device exactly as flope_crop_resize_mask does."""
+    _require_gpu()
+    dev = torch.device(device)
+    s0 = torch.empty(n_dst, dtype=torch.int32, device=dev)
+    co = torch.empty((n_dst, 8), dtype=torch.int16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().flope_lanczos4_table(int(n_src), int(n_dst), s0.data_ptr(), co.data_ptr(), _stream_ptr(dev)))
+    return s0, co
 
 
 def depth_lift(depth_raw: torch.Tensor, mask: torch.Tensor, boxes: torch.Tensor, K4, depth_div: float,
@@ -283,7 +317,9 @@ def depth_lift(depth_raw: torch.Tensor, mask: torch.Tensor, boxes: torch.Tensor,
         fmt = 0
     else:
         raise ValueError(f"depth must be uint16 or float32, got {d16.dtype}")
-    _lib.check(_lib.load().flope_depth_lift(d16.data_ptr(), fmt, mask.contiguous().data_ptr(), H, W, float(depth_div),
-                                            float(near), float(far), boxes.data_ptr(), n, k, scratch.data_ptr(),
-                                            dv.data_ptr(), rel.data_ptr(), xyz.data_ptr(), _stream_ptr(dev)))
+    mask = mask.to(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().flope_depth_lift(d16.data_ptr(), fmt, mask.contiguous().data_ptr(), H, W, float(depth_div),
+                                                float(near), float(far), boxes.data_ptr(), n, k, scratch.data_ptr(),
+                                                dv.data_ptr(), rel.data_ptr(), xyz.data_ptr(), _stream_ptr(dev)))
     return dv, rel.bool(), xyz

@@ -120,6 +120,11 @@ int flope_crop_resize_mask(const uint8_t* frame_dev, const uint8_t* mask_dev,
                            int frame_h, int frame_w, const int32_t* boxes_dev, int n,
                            int size, int out_format, void* out_dev, void* stream);
 
+/* Test hook for the call above: the Lanczos-4 tables of one axis resized n_src -> n_dst, evaluated on the device by
+ * the same code the crop kernel runs: s0_dev int32 [n_dst] (position of the first of the eight taps, unclamped),
+ * coef_dev int16 [n_dst,8] (cv2's x2048 fixed-point weights).  Parity tests compare them bit for bit with the oracle. */
+int flope_lanczos4_table(int n_src, int n_dst, int32_t* s0_dev, int16_t* coef_dev, void* stream);
+
 /* Detector post-processing of `get_bbox_mask` (fast_pose_predictor.py:50-54): sum of the n
  * instance masks (float32 [n,h,w], any values) -> clip to [0,1] -> x255 -> uint8 -> bilinear
  * resize to the frame (cv2.resize default INTER_LINEAR, 8-bit fixed-point arithmetic) ->

@@ -102,41 +102,57 @@ def shrink_mask(mask, kernel_size=3):
 
 
 def _lanczos4_coeffs(x):
-    """OpenCV interpolateLanczos4: float32 weights for taps -3..+4 at fraction x."""
+    """OpenCV interpolateLanczos4 (imgproc/src/resize.cpp) with C's evaluation types: ``x + 3`` and
+    ``x + 3 - i`` are float32 operations (left to right), the angles and the rotation recurrence double,
+    the normalisation float32."""
+    import math
     s45 = 0.70710678118654752440084436210485
     cs = [(1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45)]
     x = np.float32(x)
-    y0 = -(float(x) + 3) * np.pi * 0.25
-    s0, c0 = np.sin(y0), np.cos(y0)
+    xp3 = np.float32(x + np.float32(3))
+    y0 = -float(xp3) * math.pi * 0.25
+    s0, c0 = math.sin(y0), math.cos(y0)
     co = np.zeros(8, np.float32)
+    total = np.float32(0)
     for i in range(8):
-        y0_ = np.float32(x + np.float32(3 - i))
-        if abs(y0_) >= 1e-6:
-            y = -float(y0_) * np.pi * 0.25
+        y0_ = np.float32(xp3 - np.float32(i))
+        if abs(y0_) >= np.float32(1e-6):
+            y = -float(y0_) * math.pi * 0.25
             co[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
         else:
             co[i] = np.float32(1e30)
-    total = np.float32(0)
-    for i in range(8):
         total = np.float32(total + co[i])
-    inv = np.float32(1.0) / total
+    inv = np.float32(np.float32(1.0) / total)
     return (co * inv).astype(np.float32)
+
+
+def _resize_scale(n_src, n_dst):
+    """cv::resize with an explicit dsize: inv_scale = (double)dst / src; scale = 1. / inv_scale."""
+    return 1.0 / (float(n_dst) / float(n_src))
 
 
 def _axis_table(n_src, n_dst):
     """per destination index: (clamped source indices [8], int16-range fixed-point weights [8])"""
-    scale = n_src / n_dst
+    idx, wt, _ = _axis_table_raw(n_src, n_dst)
+    return idx, wt
+
+
+def _axis_table_raw(n_src, n_dst):
+    """-> (clamped source indices [n_dst,8], weights [n_dst,8], first-tap position s [n_dst])"""
+    scale = _resize_scale(n_src, n_dst)
     idx = np.zeros((n_dst, 8), np.int64)
     wt = np.zeros((n_dst, 8), np.int64)
+    s_all = np.zeros(n_dst, np.int64)
     for d in range(n_dst):
         f = np.float32((d + 0.5) * scale - 0.5)
         s = int(np.floor(f))
         f = np.float32(f - np.float32(s))
         co = _lanczos4_coeffs(f)
-        q = np.rint(co.astype(np.float32) * np.float32(2048)).astype(np.int64)   # round half to even
+        q = np.rint(co.astype(np.float32) * np.float32(2048)).astype(np.int64)   # cvRound: round half to even
         wt[d] = np.clip(q, -32768, 32767)
         idx[d] = np.clip(np.arange(s - 3, s + 5), 0, n_src - 1)
-    return idx, wt
+        s_all[d] = s
+    return idx, wt, s_all
 
 
 def resize_lanczos4_u8(img, size):
@@ -161,7 +177,7 @@ def resize_lanczos4_u8(img, size):
 def _linear_axis_table(src: int, dst: int):
     """cv2 resize.cpp, INTER_LINEAR coefficient tables for one axis of an 8-bit image: fixed point, 11 bits
     (INTER_RESIZE_COEF_BITS), float32 fraction exactly as `fx = (float)((dx+0.5)*scale - 0.5); sx = cvFloor(fx); fx -= sx`."""
-    scale = src / dst                                           # double
+    scale = _resize_scale(src, dst)                             # double
     f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     s0 = np.floor(f).astype(np.int64)
     fr = (f - s0.astype(np.float32)).astype(np.float32)

@@ -260,6 +260,9 @@ def _scene(seed, H=480, W=640, n=6):
 
 
 def test_crop_resize_mask_vs_oracle():
+    """Crop + cv2-style INTER_LANCZOS4 + mask multiply (fast_pose_predictor.py:108-123): BIT-EXACT against the oracle --
+    the uint8 resized image and mask (integer work) and the float32 product, which the device forms in double like the
+    reference's numpy expression and rounds once."""
     from flope_amd import engine as E
     rgb, mask, _, boxes = _scene(20)
     _, sq, _ = P.select_boxes(boxes, rgb.shape)
@@ -267,11 +270,34 @@ def test_crop_resize_mask_vs_oracle():
         sel = sq[:3] if S == 512 else sq
         got = E.crop_resize_mask(torch.from_numpy(rgb).cuda(), torch.from_numpy(mask).cuda(),
                                  torch.from_numpy(sel.astype(np.int32)).cuda(), S).cpu().numpy()
-        ref = P.crop_batch(rgb, mask, sel, S).transpose(0, 3, 1, 2)
-        assert got.shape == ref.shape
-        diff = np.abs(got - ref)
-        assert diff.max() <= 1.0 / 255 + 1e-6                                   # at most one grey level anywhere
-        assert (diff > 1e-6).mean() < 1e-3                                      # and bit-identical almost everywhere
+        ref = P.crop_batch(rgb, mask, sel, S).transpose(0, 3, 1, 2).astype(np.float32)    # the reference's torch.float32 cast
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert np.array_equal(got, ref), (S, int((got != ref).sum()), float(np.abs(got - ref).max()))
+    # an all-255 mask exposes the resized uint8 image itself: (float32)(v * (255/255.0) / 255.0) is injective in v
+    ones = np.full_like(mask, 255)
+    got = E.crop_resize_mask(torch.from_numpy(rgb).cuda(), torch.from_numpy(ones).cuda(),
+                             torch.from_numpy(sq.astype(np.int32)).cuda(), 96).cpu().numpy()
+    u8 = np.stack([P.resize_lanczos4_u8(rgb[y0:y1, x0:x1], 96) for x0, y0, x1, y1 in sq]).transpose(0, 3, 1, 2)
+    assert np.array_equal(np.rint(got * 255).astype(np.uint8), u8)
+    # 16-bit NHWC outputs = the float32 crop rounded once more (what the stem would do with it)
+    from flope_amd import _lib
+    for fmt, tdt in ((_lib.IN_F16_NHWC, torch.float16), (_lib.IN_BF16_NHWC, torch.bfloat16)):
+        g16 = E.crop_resize_mask(torch.from_numpy(rgb).cuda(), torch.from_numpy(mask).cuda(),
+                                 torch.from_numpy(sq.astype(np.int32)).cuda(), 64, fmt).cpu()
+        r16 = torch.from_numpy(P.crop_batch(rgb, mask, sq, 64).astype(np.float32)).to(tdt)
+        assert torch.equal(g16, r16)
+
+
+@pytest.mark.parametrize("n_src,n_dst", [(57, 512), (113, 512), (512, 512), (640, 224), (97, 64), (31, 100), (1000, 24),
+                                         (7, 512), (1, 16), (333, 333), (119, 512), (2, 3)])
+def test_lanczos_tables_bit_exact_vs_oracle(n_src, n_dst):
+    """The int16 x2048 coefficient tables and tap positions the crop kernel evaluates on the device (double sin/cos,
+    float normalisation, round-half-even) equal the oracle's for every destination index."""
+    from flope_amd import engine as E
+    s0, co = E.lanczos4_table(n_src, n_dst)
+    _, wt, s = P._axis_table_raw(n_src, n_dst)
+    assert np.array_equal(s0.cpu().numpy().astype(np.int64), s)
+    assert np.array_equal(co.cpu().numpy().astype(np.int64), wt), int((co.cpu().numpy() != wt).sum())
 
 
 @pytest.mark.parametrize("n,h,w,H,W", [(5, 160, 288, 1080, 1920), (3, 37, 53, 90, 160), (2, 64, 48, 40, 30), (4, 24, 32, 24, 32),
@@ -395,3 +421,121 @@ def test_detection_rows_harness_vs_oracle(state_dict, tmp_path):
     assert all(len(tok.split(".")[1]) == 7 for tok in f.read_text().split())
     write_detection_file(f, detection_rows(model, rgb, mask, boxes[-2:-1], crop_size=256))   # nothing survives
     assert f.read_text() == ""
+
+
+# ---- predictors and harnesses at the sizes / branches the reference has --------------------
+def _write_ckpt(tmp_path, state_dict, h, w, fx=600.0):
+    import yaml
+    ckpt, intr = tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=fx, fy=fx, cx=w / 2, cy=h / 2, h=h, w=w)))
+    K = np.array([[fx, 0, w / 2], [0, fx, h / 2], [0, 0, 1]])
+    return str(ckpt), str(intr), K
+
+
+def test_pose_predictor_teacher_front_end_vs_oracle(state_dict, tmp_path):
+    """PosePredictor (pose_predictor.py:69-186) with the detector / segmenter outputs given: `filter_very_large_bb`
+    (:83) drops the oversized box BEFORE squarify, depth is in 1e-4 m units (`/10000`, :118), `None` contracts
+    (:76-78, :114-115, :131-132)."""
+    from sunflower.predictor.pose_predictor import PosePredictor
+    rgb, mask, depth, boxes = _scene(31)
+    depth10k = (depth.astype(np.int64) * 10).astype(np.uint16)                # same scene, RealSense-D405 units
+    big = np.array([[40, 30, 600, 440]], dtype=boxes.dtype)                    # in frame once squarified?  no matter: area > 5 x median
+    boxes_all = np.concatenate([boxes[:3], big, boxes[3:]])
+    ckpt, intr, K = _write_ckpt(tmp_path, state_dict, 480, 640)
+    seen = {}
+    def segmenter(img, bb):
+        seen["bb"] = bb
+        return mask
+    pred = PosePredictor("cuda", ckpt, intr, detector=lambda img: boxes_all, segmenter=segmenter)
+    Rt = pred.get_flower_poses(rgb, depth10k)
+    kept = P.filter_very_large_bb(boxes_all)
+    assert len(kept) == len(boxes_all) - 1 and seen["bb"] == kept.tolist()    # SAM sees the filtered boxes (:87-88)
+    ref = P.get_flower_poses(lambda b: O.forward(state_dict, b), O.procrustes_to_rotmat, rgb, depth10k, kept, mask, K,
+                             depth_div=10000.0)
+    assert Rt.dtype == np.float64 and Rt.shape == ref.shape and Rt.shape[0] >= 3
+    assert np.abs(Rt[:, :3, :3] - ref[:, :3, :3]).max() <= 1e-3
+    assert np.linalg.norm(Rt[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
+    # the same frame read with the wrong scale (/1000 semantics) puts every flower beyond the far plane -> None (:131-132)
+    far = PosePredictor("cuda", ckpt, intr, detector=lambda img: boxes_all, segmenter=lambda i, b: mask)
+    assert far.get_flower_poses(rgb, (depth.astype(np.int64) * 100).clip(0, 65535).astype(np.uint16)) is None
+    # no detection at all: the reference's detector returns an array of shape (0,) (:76-78)
+    none = PosePredictor("cuda", ckpt, intr, detector=lambda img: np.array([]), segmenter=lambda i, b: mask)
+    assert none.get_flower_poses(rgb, depth10k) is None
+    # every box leaves the frame once squarified (:114-115)
+    edge = PosePredictor("cuda", ckpt, intr, detector=lambda img: boxes[-2:-1], segmenter=lambda i, b: mask)
+    assert edge.get_flower_poses(rgb, depth10k) is None
+
+
+def test_live_pose_loop_over_frames(state_dict, tmp_path):
+    """scripts/live_pose.py:31-41: frames -> get_flower_poses -> [N,4,4] | None, frame by frame."""
+    from flope_amd.harness import live_pose_loop
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor
+    scenes = [_scene(41), _scene(42), _scene(43)]
+    ckpt, intr, K = _write_ckpt(tmp_path, state_dict, 480, 640)
+    it = iter(scenes)
+    cur = {}
+    def detector(img):
+        return cur["boxes"], cur["mask"]
+    pred = FastPosePredictor("cuda", detector, ckpt, intr)
+    def frames():
+        for i, (rgb, mask, depth, boxes) in enumerate(scenes):
+            cur["boxes"], cur["mask"] = (boxes[-1:], mask) if i == 1 else (boxes, mask)   # frame 1: nothing usable
+            yield rgb, depth
+    out = live_pose_loop(pred, frames())
+    assert len(out) == 3 and out[1] is None
+    for i in (0, 2):
+        rgb, mask, depth, boxes = scenes[i]
+        ref = P.get_flower_poses(lambda b: O.forward(state_dict, b), O.procrustes_to_rotmat, rgb, depth, boxes, mask, K)
+        assert out[i].shape == ref.shape and np.abs(out[i] - ref)[:, :3, :3].max() <= 1e-3
+        assert np.linalg.norm(out[i][:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
+
+
+def test_end_to_end_1080p_31_boxes_vs_oracle(state_dict, tmp_path):
+    """BASELINE configs[2] at its own size: one 1080 x 1920 frame, 31 detector boxes, 512 x 512 crops (the
+    reference's crop size), detections given (the detector itself is tested in test_gpu_yolo.py)."""
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor
+    rgb, mask, depth, boxes = _scene(51, H=1080, W=1920, n=29)
+    assert len(boxes) == 31
+    ckpt, intr, K = _write_ckpt(tmp_path, state_dict, 1080, 1920, fx=1400.0)
+    pred = FastPosePredictor("cuda", lambda img: (boxes, mask), ckpt, intr)
+    Rt = pred.get_flower_poses(rgb, depth)
+    ref = P.get_flower_poses(lambda b: O.forward(state_dict, b), O.procrustes_to_rotmat, rgb, depth, boxes, mask, K)
+    assert Rt.shape == ref.shape and Rt.shape[0] >= 20
+    assert np.abs(Rt[:, :3, :3] - ref[:, :3, :3]).max() <= 1e-3                 # rot err
+    assert np.linalg.norm(Rt[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5   # trans err (m)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_rotation_error_vs_conditioning_of_M(state_dict, dtype):
+    """Where the 1e-3 claim holds.  Procrustes amplifies an error dM in the 3x3 head output by ~ |dM| / (s2 + s3)
+    (s_i = singular values of M).  The synthetic head is well conditioned by construction (fc_rot.bias = vec(R0)), so
+    the sweep scales that bias down: M = a * R0 + W h.  Asserted: max |dR| * (s2 + s3) stays bounded by the 16-bit
+    trunk's |dM| (it is the same trunk error at every a), f16 meets 1e-3 down to (s2 + s3) >= 0.35 and bf16 only
+    for well-conditioned heads.  The measured table is printed (pytest -s) and quoted in DESIGN.md."""
+    torch.manual_seed(0)
+    x = torch.rand(16, 3, 224, 224)
+    rows = []
+    e = _engine(state_dict, 224, 224, 16, dtype)
+    for a in (1.0, 0.5, 0.25, 0.1, 0.05):
+        sd = dict(state_dict)
+        sd["fc_rot.bias"] = state_dict["fc_rot.bias"] * a
+        e.load_state_dict(sd)
+        r9, R = _run(e, x)
+        ref9 = O.forward(sd, x)
+        Rref = O.procrustes_to_rotmat(ref9)
+        sv = torch.linalg.svdvals(ref9.double().view(-1, 3, 3))
+        gap = (sv[:, 1] + sv[:, 2])
+        dR = (R - Rref).abs().amax(dim=(1, 2)).double()
+        dM = (r9 - ref9).abs().amax(dim=1).double()
+        rows.append((a, float(gap.min()), float(gap.median()), float(dM.max()), float(dR.max()), float((dR * gap).max())))
+    e.close()
+    print(f"\n{dtype}: bias scale | min(s2+s3) | median | max|dM| | max|dR| | max |dR|*(s2+s3)")
+    for r in rows:
+        print("   %.2f | %.3f | %.3f | %.2e | %.2e | %.2e" % r)
+    tol_M = 1.5e-3 if dtype == "f16" else 1.2e-2
+    for a, gmin, gmed, dM, dR, k in rows:
+        assert dM <= tol_M, (a, dM)
+        assert k <= 3 * tol_M, (a, k)                     # |dR| <~ |dM| / (s2 + s3), constant ~ sqrt(2)..3
+        if dtype == "f16" and gmin >= 0.35:
+            assert dR <= 1e-3, (a, gmin, dR)

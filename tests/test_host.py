@@ -247,3 +247,77 @@ def test_tools_and_entry_points_compile():
     with tempfile.TemporaryDirectory() as tmp:
         for f in files:
             py_compile.compile(f, doraise=True, cfile=os.path.join(tmp, "check.pyc"))
+
+
+# ---- PosePredictor: the reference's own call shape (pose_predictor.py:41-66) -------------------------------------
+_GDINO_STUB = '''
+import numpy as np
+CALLS = []
+class GroundingDINO:
+    def __init__(self, device, text_prompt, box_th=0.2, text_th=0.3, obj_filter=None):
+        CALLS.append(("gdino", device, text_prompt, box_th, text_th, obj_filter))
+    def detect(self, image):
+        return np.array([[10, 10, 40, 50], [60, 20, 100, 70]])
+'''
+_SAM_STUB = '''
+import numpy as np
+CALLS = []
+class SAM:
+    def __init__(self, device):
+        CALLS.append(("sam", device))
+    def get_segmentation_mask(self, image, bounding_boxes):
+        CALLS.append(("mask", type(image).__name__, bounding_boxes))
+        return np.zeros((image.size[1], image.size[0]), np.uint8)
+'''
+
+
+def _ckpt_and_intrinsics(tmp_path, state_dict, h=480, w=640):
+    import yaml
+    ckpt, intr = tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=600.0, fy=600.0, cx=w / 2, cy=h / 2, h=h, w=w)))
+    return str(ckpt), str(intr)
+
+
+def test_pose_predictor_reference_call_shape_builds_gdino_and_sam(tmp_path, state_dict, monkeypatch):
+    """`PosePredictor(device, posenet_path, intrin_path, debug)` with no injection -- exactly scripts/live_pose.py:22-28 --
+    imports sunflower.models.{grounding_dino,sam} through the namespace package and builds them with the reference's
+    arguments (pose_predictor.py:55-60).  The stubs stand in for the reference tree's two hub-model wrappers."""
+    import importlib
+    import sys
+    stub = tmp_path / "reftree" / "sunflower" / "models"
+    stub.mkdir(parents=True)
+    (stub / "grounding_dino.py").write_text(_GDINO_STUB)
+    (stub / "sam.py").write_text(_SAM_STUB)
+    monkeypatch.syspath_prepend(str(tmp_path / "reftree"))            # the reference tree, next to the mirror
+    for name in ("sunflower.models.grounding_dino", "sunflower.models.sam"):
+        sys.modules.pop(name, None)
+    importlib.invalidate_caches()
+    from sunflower.predictor.pose_predictor import PosePredictor
+    ckpt, intr = _ckpt_and_intrinsics(tmp_path, state_dict)
+    pred = PosePredictor("cpu", ckpt, intr, True)                     # construction touches no GPU
+    gd, sm = sys.modules["sunflower.models.grounding_dino"], sys.modules["sunflower.models.sam"]
+    assert gd.CALLS == [("gdino", "cpu", "white flower.", 0.3, 0.3, "white flower")]
+    assert sm.CALLS == [("sam", "cpu")]
+    assert pred.detector(np.zeros((480, 640, 3), np.uint8)).shape == (2, 4)
+    m = pred.segmenter(np.zeros((480, 640, 3), np.uint8), [[10, 10, 40, 50]])
+    assert m.shape == (480, 640) and sm.CALLS[-1] == ("mask", "Image", [[10, 10, 40, 50]])
+    assert pred.K[0][0] == 600.0 and (pred.height, pred.width) == (480, 640)
+    # the posenet mirror inside it is the HIP one: a CPU crop batch must raise, never compute on the host
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        pred.posenet(torch.rand(1, 3, 64, 64))
+    for name in ("sunflower.models.grounding_dino", "sunflower.models.sam"):
+        sys.modules.pop(name, None)
+
+
+def test_pose_predictor_without_front_end_names_what_is_missing(tmp_path, state_dict):
+    import sys
+    for name in ("sunflower.models.grounding_dino", "sunflower.models.sam"):
+        sys.modules.pop(name, None)
+    from sunflower.predictor.pose_predictor import PosePredictor
+    ckpt, intr = _ckpt_and_intrinsics(tmp_path, state_dict)
+    with pytest.raises(ImportError, match="grounding_dino"):
+        PosePredictor("cpu", ckpt, intr)
+    # injected callables need no reference modules
+    p = PosePredictor("cpu", ckpt, intr, detector=lambda rgb: np.zeros((0,)), segmenter=lambda rgb, bb: None)
+    assert p.get_flower_poses(np.zeros((480, 640, 3), np.uint8), np.zeros((480, 640), np.uint16)) is None   # :76-78
