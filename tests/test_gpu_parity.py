@@ -440,8 +440,8 @@ def test_pose_predictor_teacher_front_end_vs_oracle(state_dict, tmp_path):
     from sunflower.predictor.pose_predictor import PosePredictor
     rgb, mask, depth, boxes = _scene(31)
     depth10k = (depth.astype(np.int64) * 10).astype(np.uint16)                # same scene, RealSense-D405 units
-    big = np.array([[40, 30, 600, 440]], dtype=boxes.dtype)                    # in frame once squarified?  no matter: area > 5 x median
-    boxes_all = np.concatenate([boxes[:3], big, boxes[3:]])
+    big = np.array([[40, 30, 600, 440]])                                       # area > 5 x median: dropped before squarify
+    boxes_all = np.concatenate([boxes[:3], big, boxes[3:]]).astype(np.int64)   # GroundingDINO.detect returns python ints -> int64
     ckpt, intr, K = _write_ckpt(tmp_path, state_dict, 480, 640)
     seen = {}
     def segmenter(img, bb):
@@ -508,18 +508,23 @@ def test_end_to_end_1080p_31_boxes_vs_oracle(state_dict, tmp_path):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_rotation_error_vs_conditioning_of_M(state_dict, dtype):
-    """Where the 1e-3 claim holds.  Procrustes amplifies an error dM in the 3x3 head output by ~ |dM| / (s2 + s3)
-    (s_i = singular values of M).  The synthetic head is well conditioned by construction (fc_rot.bias = vec(R0)), so
-    the sweep scales that bias down: M = a * R0 + W h.  Asserted: max |dR| * (s2 + s3) stays bounded by the 16-bit
-    trunk's |dM| (it is the same trunk error at every a), f16 meets 1e-3 down to (s2 + s3) >= 0.35 and bf16 only
-    for well-conditioned heads.  The measured table is printed (pytest -s) and quoted in DESIGN.md."""
+    """Where the 1e-3 claim holds.  Procrustes amplifies an error dM of the 3x3 head output by ~ |dM| / (s2 + s3)
+    (s_i = singular values of M).  The synthetic head is well conditioned by construction (fc_rot.bias = vec(R0),
+    s ~ 1.9 / 0.8 / 0.4).  The sweep keeps the trunk (and therefore its 16-bit error dM) and re-biases the head so that
+    M_i = a * R0 + (W h_i - mean_j W h_j): singular values ~ a, i.e. (s2 + s3) ~ 2a, down to a = 0.01.
+    Asserted: |dR| * (s2 + s3) <= 1.5 |dM| at every a (the amplification law, so the claim's domain can be stated),
+    f16 meets 1e-3 wherever (s2 + s3) >= 0.5, bf16 only wherever (s2 + s3) >= 3 |dM| / 1e-3.
+    The measured table is printed (pytest -s) and quoted in DESIGN.md."""
     torch.manual_seed(0)
     x = torch.rand(16, 3, 224, 224)
     rows = []
     e = _engine(state_dict, 224, 224, 16, dtype)
-    for a in (1.0, 0.5, 0.25, 0.1, 0.05):
+    sd0 = dict(state_dict)
+    sd0["fc_rot.bias"] = torch.zeros(9)
+    mean_wh = O.forward(sd0, x).mean(0)
+    for a in (1.0, 0.3, 0.1, 0.03, 0.01):
         sd = dict(state_dict)
-        sd["fc_rot.bias"] = state_dict["fc_rot.bias"] * a
+        sd["fc_rot.bias"] = state_dict["fc_rot.bias"] * a - mean_wh
         e.load_state_dict(sd)
         r9, R = _run(e, x)
         ref9 = O.forward(sd, x)
@@ -530,12 +535,13 @@ def test_rotation_error_vs_conditioning_of_M(state_dict, dtype):
         dM = (r9 - ref9).abs().amax(dim=1).double()
         rows.append((a, float(gap.min()), float(gap.median()), float(dM.max()), float(dR.max()), float((dR * gap).max())))
     e.close()
-    print(f"\n{dtype}: bias scale | min(s2+s3) | median | max|dM| | max|dR| | max |dR|*(s2+s3)")
+    print(f"\n{dtype}: bias scale a | min(s2+s3) | median | max|dM| | max|dR| | max |dR|*(s2+s3)")
     for r in rows:
-        print("   %.2f | %.3f | %.3f | %.2e | %.2e | %.2e" % r)
-    tol_M = 1.5e-3 if dtype == "f16" else 1.2e-2
+        print("   %.2f | %.4f | %.4f | %.2e | %.2e | %.2e" % r)
+    tol_M = 1.0e-3 if dtype == "f16" else 8e-3
+    assert rows[0][1] > 1.5 and rows[-1][1] < 0.05               # the sweep really spans two decades of conditioning
     for a, gmin, gmed, dM, dR, k in rows:
         assert dM <= tol_M, (a, dM)
-        assert k <= 3 * tol_M, (a, k)                     # |dR| <~ |dM| / (s2 + s3), constant ~ sqrt(2)..3
-        if dtype == "f16" and gmin >= 0.35:
+        assert k <= 1.5 * dM + 1e-6, (a, k, dM)
+        if gmin >= (0.5 if dtype == "f16" else 3 * dM / 1e-3):
             assert dR <= 1e-3, (a, gmin, dR)
