@@ -42,6 +42,16 @@ SIGNATURES = {
     "flope_launch_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_D)]),
     "flope_describe_plan": (_I, [_P, C.c_char_p, _I]),
     "flope_version": (C.c_char_p, []),
+    "flope_yolo_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "flope_yolo_destroy": (_I, [_P]),
+    "flope_yolo_last_error": (C.c_char_p, [_P]),
+    "flope_yolo_input_size": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "flope_yolo_load_weights": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_I), C.POINTER(_P)]),
+    "flope_yolo_detect": (_I, [_P, _P, _F, _F, _I, _P, _P, _P, _P]),
+    "flope_yolo_forward": (_I, [_P, _P, _P]),
+    "flope_yolo_read_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _P]),
+    "flope_yolo_flops": (_D, [_P]),
+    "flope_yolo_launches": (_I, [_P]),
     "flope_tf_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "flope_tf_destroy": (_I, [_P]),
     "flope_tf_last_error": (C.c_char_p, [_P]),

@@ -446,6 +446,15 @@ __global__ void resize_linear_u8_kernel(const uint8_t* in, int h, int w, uint8_t
   out[(size_t)y * W + x] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// cv2.resize(img, (W, H)) (INTER_LINEAR, 8-bit) of a device image: shared with the detector front end (yolo_engine.hip)
+extern "C" int flope_resize_linear_u8_launch(const uint8_t* in, int h, int w, uint8_t* out, int H, int W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (h == H && w == W) return (int)hipMemcpyAsync(out, in, (size_t)H * W, hipMemcpyDeviceToDevice, st);
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, in, h, w, out, H, W,
+                     1.0 / ((double)W / w), 1.0 / ((double)H / h));
+  return (int)hipGetLastError();
+}
+
 extern "C" int flope_merge_masks_resize(const float* masks_dev, int n, int h, int w, uint8_t* scratch_dev,
                                         uint8_t* out_dev, int H, int W, void* stream) {
   if (n < 0 || h < 1 || w < 1 || H < 1 || W < 1 || !out_dev || (n > 0 && !masks_dev)) return -1;

@@ -1,0 +1,84 @@
+// Launch-parameter structs of the YOLO11-seg detector kernels (yolo.hip) -- the front end of
+// FastPosePredictor.get_bbox_mask (reference sunflower/predictor/fast_pose_predictor.py:36,44-57; the network
+// itself lives in ultralytics 8.3.27, environment.yml:231).  gfx950 only.
+//
+// Activations are NHWC 16-bit *views*: a pointer (already offset to the view's first channel), the channel
+// count of the view and the pixel stride `ld` of the buffer it lives in (in elements).  Concat / chunk / split
+// of the reference graph are therefore free: producers write straight into channel slices of the consumer's
+// buffer.  No spatial padding: border taps are redirected to a 16-byte zero page.
+#pragma once
+#include <stdint.h>
+
+struct YConvP {
+  const void* in;  int Hi, Wi, Cin, ldi;     // Cin % 8 == 0
+  void* out;       int Ho, Wo, Cout, ldo;    // out_mode 1: float32 rows, ldo in floats
+  const void* res; int ldr;                  // optional residual view, added AFTER the activation (nullptr = none)
+  const void* w;                             // [rows = ceil(Cout / (16 NT)) * 16 NT][Kp] 16-bit, rows permuted (pack_yconv)
+  const float* bias;                         // [rows]
+  const void* zero;                          // >= 16 bytes of zeros
+  int k, stride;                             // 1 or 3 (pad = k / 2); 1 or 2
+  int act;                                   // 1 = SiLU
+  int M;                                     // Ho * Wo
+  int cg;                                    // Cin / 8: 16-byte granules per tap
+  unsigned cg_mg, cg_sh;                     // n / cg as multiply-shift
+  int ksteps;                                // Kp / 32
+  int out_mode;                              // 0: 16-bit view, 1: float32 view, 2: 2x2 stride-2 transposed conv scatter (16-bit)
+  int dc;                                    // out_mode 2: real output channels (rows = 4 * dc, row = (dy*2+dx)*dc + co)
+};
+
+struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU) (+ add)
+  const void* in; int H, W, C, ldi;
+  void* out; int ldo;
+  const void* add; int lda;                  // optional: out = dw(in) + add   (PSA: attention output + positional conv)
+  const float* w;                            // [9][C]
+  const float* bias;                         // [C]
+  int act;
+  int blk, blk_stride, blk_off;              // blk != 0: input channel of output channel c = (c / blk) * blk_stride + blk_off + c % blk
+};
+
+struct YPoolP { const void* in; int H, W, C, ldi; void* out; int ldo; };           // 5x5 s1 p2 max-pool, -inf border
+struct YUpP { const void* in; int H, W, C, ldi; void* out; int ldo; };             // nearest 2x: out is [2H][2W]
+
+struct YAttnP {          // ultralytics Attention: per head q(32) k(32) v(64) interleaved in the qkv map
+  const void* qkv; int N, heads, ld;         // ld = heads * 128
+  void* out; int ldo;                        // [N][heads * 64]
+  float scale;
+};
+
+struct YLetterP {        // uint8 BGR frame -> letterboxed RGB / 255, 8-channel 16-bit NHWC (channels 3..7 zero)
+  const uint8_t* frame; int H, W;
+  void* out; int h, w;                       // letterboxed size
+  int nh, nw, top, left;                     // resized content size and its offset
+  double sx, sy;                             // cv::resize scale = 1 / ((double)n_dst / n_src)
+};
+
+struct YDecodeP {
+  const float* pred; int A, no, nc;          // [A][no]: 64 DFL logits, nc class logits, 32 mask coefficients
+  int lvl_a0[4], lvl_w[3], lvl_stride[3];    // anchors of level l: [lvl_a0[l], lvl_a0[l+1])
+  float conf;
+  float* cand_box;                           // [A][4] xyxy (letterbox pixels)
+  float* cand_conf;                          // [A]
+  int* cand_cls;                             // [A]
+  int* cand_list; int* cand_count; int cand_cap;   // anchors that pass the confidence threshold (unordered)
+};
+
+struct YNmsP {
+  const float* cand_box; const float* cand_conf; const int* cand_cls;
+  const int* cand_list; const int* cand_count; int cand_cap;
+  float iou; int max_det; float max_wh;
+  // letterbox -> frame (ops.scale_boxes): x = (x - pad_x) / gain clipped to [0, W]
+  float pad_x, pad_y, gain; int frame_w, frame_h;
+  float* det;                                // [max_det][8]: frame xyxy, conf, cls, letterbox-box index (anchor), 0
+  float* det_lb;                             // [max_det][4] letterbox xyxy (mask cropping)
+  int* det_anchor;                           // [max_det]
+  int* det_count;
+};
+
+struct YMaskP {
+  const void* proto; int mh, mw;             // [mh][mw][32] 16-bit
+  const float* pred; int no, nc;             // coefficient row of anchor a: pred + a * no + 64 + nc
+  const float* det_lb; const int* det_anchor; const int* det_count; int max_det;
+  int ih, iw;                                // letterboxed input size
+  float* low;                                // [max_det][mh][mw] cropped low-resolution masks
+  uint8_t* merged;                           // [ih][iw] 255 where any instance mask is set
+};

@@ -1,0 +1,626 @@
+// Kernels of the YOLO11-seg detector front end (reference sunflower/predictor/fast_pose_predictor.py:36,44-57:
+// `self.yolo(image)` + the mask / box post-processing of get_bbox_mask; network arithmetic = ultralytics 8.3.27,
+// not vendored by the reference -- restated from the published algorithm, PARITY UNPINNED against ultralytics).
+//
+//   yconv_kernel     Conv2d (1x1 / 3x3, stride 1 / 2) + folded BatchNorm + SiLU (+ residual) as an implicit GEMM on
+//                    v_mfma_f32_16x16x32_{f16,bf16}: weights are the A operand, 16 pixels the B operand, so a lane
+//                    ends with one pixel x 4*NT consecutive channels and the epilogue (bias, SiLU = x * sigmoid(x),
+//                    residual, 16-bit pack) stays in registers.  Operand fragments are 16-byte global loads
+//                    (pixels: 8 consecutive channels of one tap; weights: 8 consecutive k of one output row) -- this
+//                    network is 100+ small layers at one frame, i.e. launch- and latency-bound, not MFMA-bound.
+//                    Also: plain Conv2d with bias (float32 rows of the prediction tensor) and the 2x2 stride-2
+//                    ConvTranspose2d of the Proto block (a 1x1 GEMM with a pixel-shuffle store).
+//   ydw / ypool / yup / yattn   depthwise 3x3, SPPF's 5x5 max-pool, nearest 2x upsample, C2PSA attention
+//   yletter          LetterBox (cv2 INTER_LINEAR 8-bit arithmetic) + BGR->RGB + /255
+//   ydecode / ynms   Detect._inference (DFL expectation, dist2bbox) and ops.non_max_suppression
+//   ymask_*          ops.process_mask + the sum/clip/x255 of get_bbox_mask
+#include "common.h"
+#include "yolo.h"
+
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+
+template <typename T> __device__ __forceinline__ float ld16(const void* p) { return to_f32<T>(*(const T*)p); }
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int NT, bool K3>
+__global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int MTW = 2, CB = 16 * NT;               // pixel tiles per wave, channels per block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int m_base = (blockIdx.x * 4 + wave) * (16 * MTW);
+  if (m_base >= p.M) return;
+  const int nblk = blockIdx.y;
+  const int pad = K3 ? 1 : 0;
+  const size_t Kp2 = (size_t)p.ksteps * 64;          // bytes per weight row
+  int iy0[MTW], ix0[MTW];
+  bool pv[MTW];
+#pragma unroll
+  for (int pt = 0; pt < MTW; ++pt) {
+    const int m = m_base + pt * 16 + c16;
+    pv[pt] = m < p.M;
+    const int mm = pv[pt] ? m : p.M - 1;
+    const int oy = mm / p.Wo, ox = mm - oy * p.Wo;
+    iy0[pt] = oy * p.stride - pad;
+    ix0[pt] = ox * p.stride - pad;
+  }
+  const char* const wrow = (const char*)p.w + (size_t)(nblk * CB + c16) * Kp2 + g * 16;
+  const char* const in = (const char*)p.in;
+  const char* const zero = (const char*)p.zero;
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const f32x4 b = *(const f32x4*)(p.bias + nblk * CB + ct * 16 + g * 4);     // bias is stored in packed-row order
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt) acc[pt][ct] = b;
+  }
+  auto load_step = [&](int ks, frag (&wf)[NT], frag (&xf)[MTW]) {
+    const int kg = ks * 4 + g;
+    int c8, ky = 0, kx = 0;
+    bool tapok;
+    if (K3) {
+      const int tap = fastdiv(kg, p.cg_mg, p.cg_sh);
+      c8 = kg - tap * p.cg;
+      ky = (tap * 11) >> 5;
+      kx = tap - 3 * ky;
+      tapok = tap < 9;
+    } else {
+      c8 = kg;
+      tapok = kg < p.cg;
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(wrow + (size_t)ct * 16 * Kp2 + (size_t)ks * 64);
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt) {
+      const int iy = iy0[pt] + ky, ix = ix0[pt] + kx;
+      const bool ok = pv[pt] && tapok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const char* a = ok ? in + ((size_t)(iy * p.Wi + ix) * p.ldi + c8 * 8) * 2 : zero;
+      xf[pt] = *(const frag*)a;
+    }
+  };
+  frag wf[2][NT], xf[2][MTW];
+  load_step(0, wf[0], xf[0]);
+  for (int ks = 0; ks < p.ksteps; ks += 2) {          // two steps per trip: both register sets are compile-time indexed
+    if (ks + 1 < p.ksteps) load_step(ks + 1, wf[1], xf[1]);
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[0][ct], xf[0][pt], acc[pt][ct]);
+    if (ks + 1 < p.ksteps) {
+      if (ks + 2 < p.ksteps) load_step(ks + 2, wf[0], xf[0]);
+#pragma unroll
+      for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[1][ct], xf[1][pt], acc[pt][ct]);
+    }
+  }
+  // ---- epilogue: this lane = pixel c16 of each tile x channels ch0 .. ch0 + 4 NT - 1
+  const int ch0 = nblk * CB + g * 4 * NT;
+#pragma unroll
+  for (int pt = 0; pt < MTW; ++pt) {
+    if (!pv[pt]) continue;
+    const int m = m_base + pt * 16 + c16;
+    float v[4 * NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = acc[pt][ct][q];
+        v[ct * 4 + q] = p.act ? silu(a) : a;
+      }
+    if (p.out_mode == 1) {                             // float32 prediction rows (Detect / Segment heads)
+      float* o = (float*)p.out + (size_t)m * p.ldo;
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i)
+        if (ch0 + i < p.Cout) o[ch0 + i] = v[i];
+      continue;
+    }
+    size_t opix;
+    int och = ch0;
+    if (p.out_mode == 2) {                             // ConvTranspose2d 2x2 s2: row block -> (dy, dx) quadrant
+      const int quad = (nblk * CB) / p.dc;
+      const int oy = m / p.Wo, ox = m - oy * p.Wo;
+      opix = (size_t)(2 * oy + (quad >> 1)) * (2 * p.Wo) + 2 * ox + (quad & 1);
+      och = ch0 - quad * p.dc;
+    } else {
+      opix = (size_t)m;
+    }
+    char* o = (char*)p.out + (opix * p.ldo + och) * 2;
+    const bool full = p.out_mode == 2 || ch0 + 4 * NT <= p.Cout;
+    if (full) {
+      if (p.res) {
+        const char* r = (const char*)p.res + ((size_t)m * p.ldr + ch0) * 2;
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) v[i] += ld16<T>(r + i * 2);
+      }
+      unsigned w[2 * NT];
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) w[i] = pk_out16<T>(pack2<T>(v[2 * i], v[2 * i + 1]), false);
+      if constexpr (NT == 1) *(u32x2*)o = u32x2{w[0], w[1]};
+      else {
+#pragma unroll
+        for (int i = 0; i < NT / 2; ++i) *(u32x4*)(o + i * 16) = u32x4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i)
+        if (ch0 + i < p.Cout) {
+          float x = v[i];
+          if (p.res) x += ld16<T>((const char*)p.res + ((size_t)m * p.ldr + ch0 + i) * 2);
+          *(T*)(o + i * 2) = from_f32<T>(x);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ydw_kernel(const YDwP p) {
+  const int c8n = p.C >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.H * p.W * c8n) return;
+  const int pix = idx / c8n, c0 = (idx - pix * c8n) * 8;
+  const int y = pix / p.W, x = pix - y * p.W;
+  const int ci0 = p.blk ? (c0 / p.blk) * p.blk_stride + p.blk_off + c0 % p.blk : c0;
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = p.bias[c0 + i];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+    if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+    const u32x4 v = *(const u32x4*)((const char*)p.in + ((size_t)(iy * p.W + ix) * p.ldi + ci0) * 2);
+    const float* w = p.w + t * p.C + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[2 * q] += unpack_lo<T>(v[q]) * w[2 * q];
+      a[2 * q + 1] += unpack_hi<T>(v[q]) * w[2 * q + 1];
+    }
+  }
+  if (p.act)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = silu(a[i]);
+  if (p.add) {
+    const u32x4 v = *(const u32x4*)((const char*)p.add + ((size_t)pix * p.lda + c0) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[2 * q] += unpack_lo<T>(v[q]); a[2 * q + 1] += unpack_hi<T>(v[q]); }
+  }
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = pk_out16<T>(pack2<T>(a[2 * q], a[2 * q + 1]), false);
+  *(u32x4*)((char*)p.out + ((size_t)pix * p.ldo + c0) * 2) = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ypool_kernel(const YPoolP p) {
+  const int c8n = p.C >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.H * p.W * c8n) return;
+  const int pix = idx / c8n, c0 = (idx - pix * c8n) * 8;
+  const int y = pix / p.W, x = pix - y * p.W;
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = -3.0e38f;
+  for (int dy = -2; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int iy = y + dy, ix = x + dx;
+      if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+      const u32x4 v = *(const u32x4*)((const char*)p.in + ((size_t)(iy * p.W + ix) * p.ldi + c0) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[2 * q] = fmaxf(a[2 * q], unpack_lo<T>(v[q])); a[2 * q + 1] = fmaxf(a[2 * q + 1], unpack_hi<T>(v[q])); }
+    }
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = pack2<T>(a[2 * q], a[2 * q + 1]);
+  *(u32x4*)((char*)p.out + ((size_t)pix * p.ldo + c0) * 2) = o;
+}
+
+__global__ __launch_bounds__(256) void yup_kernel(const YUpP p) {
+  const int c8n = p.C >> 3, W2 = 2 * p.W;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4 * p.H * p.W * c8n) return;
+  const int pix = idx / c8n, c0 = (idx - pix * c8n) * 8;
+  const int y = pix / W2, x = pix - y * W2;
+  *(u32x4*)((char*)p.out + ((size_t)pix * p.ldo + c0) * 2) =
+      *(const u32x4*)((const char*)p.in + ((size_t)((y >> 1) * p.W + (x >> 1)) * p.ldi + c0) * 2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention of one C2PSA block: out[i, h*64 + d] = sum_j softmax_j(scale * q_i . k_j) v_j[d], float32 arithmetic.
+// One workgroup = 16 queries of one head; 16 lanes share a query (keys j = lane mod 16 in the score passes, output
+// dims 4*lane .. 4*lane+3 in the value pass); scores live in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void yattn_kernel(const YAttnP p) {
+  extern __shared__ float S[];                         // [16][N]
+  const int tid = threadIdx.x, ql = tid >> 4, kl = tid & 15;
+  const int h = blockIdx.y;
+  const int qi = min(blockIdx.x * 16 + ql, p.N - 1);
+  const char* base = (const char*)p.qkv + (size_t)h * 128 * 2;
+  float q[32];
+  {
+    const char* qp = base + (size_t)qi * p.ld * 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 v = *(const u32x4*)(qp + c * 16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { q[c * 8 + 2 * k] = unpack_lo<T>(v[k]) * p.scale; q[c * 8 + 2 * k + 1] = unpack_hi<T>(v[k]) * p.scale; }
+    }
+  }
+  float* Sq = S + (size_t)ql * p.N;
+  float mx = -3.0e38f;
+  for (int j = kl; j < p.N; j += 16) {
+    const char* kp = base + (size_t)j * p.ld * 2 + 64;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 v = *(const u32x4*)(kp + c * 16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += q[c * 8 + 2 * k] * unpack_lo<T>(v[k]) + q[c * 8 + 2 * k + 1] * unpack_hi<T>(v[k]);
+    }
+    Sq[j] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+  float l = 0.f;
+  for (int j = kl; j < p.N; j += 16) {
+    const float e = __expf(Sq[j] - mx);
+    Sq[j] = e;
+    l += e;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 16);
+  __syncthreads();
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const char* vp = base + 128 + kl * 8;
+  for (int j = 0; j < p.N; ++j) {
+    const float e = Sq[j];
+    const u32x2 v = *(const u32x2*)(vp + (size_t)j * p.ld * 2);
+    a0 += e * unpack_lo<T>(v[0]); a1 += e * unpack_hi<T>(v[0]);
+    a2 += e * unpack_lo<T>(v[1]); a3 += e * unpack_hi<T>(v[1]);
+  }
+  if (blockIdx.x * 16 + ql < p.N) {
+    const float inv = 1.f / l;
+    *(u32x2*)((char*)p.out + ((size_t)qi * p.ldo + h * 64 + kl * 4) * 2) =
+        u32x2{pack2<T>(a0 * inv, a1 * inv), pack2<T>(a2 * inv, a3 * inv)};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cv2 INTER_LINEAR tap of an 8-bit image (same arithmetic as prep.hip's resize_linear_u8_kernel)
+__device__ __forceinline__ void lin_tap(int d, int src, double scale, int* s0, int* s1, int* a0, int* a1) {
+  const float f = (float)__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5);
+  int s = (int)floorf(f);
+  float fr = __fsub_rn(f, (float)s);
+  if (s < 0) { fr = 0.f; s = 0; }
+  if (s >= src - 1) { fr = 0.f; s = src - 1; }
+  *a1 = (int)rintf(__fmul_rn(fr, 2048.f));
+  *a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fr), 2048.f));
+  *s0 = s;
+  *s1 = min(s + 1, src - 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void yletter_kernel(const YLetterP p) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.h * p.w) return;
+  const int y = idx / p.w, x = idx - y * p.w;
+  int bgr[3] = {114, 114, 114};
+  const int cy = y - p.top, cx = x - p.left;
+  if ((unsigned)cy < (unsigned)p.nh && (unsigned)cx < (unsigned)p.nw) {
+    if (p.nh == p.H && p.nw == p.W) {
+      const uint8_t* s = p.frame + ((size_t)cy * p.W + cx) * 3;
+      bgr[0] = s[0]; bgr[1] = s[1]; bgr[2] = s[2];
+    } else {
+      int x0, x1, a0, a1, y0, y1, b0, b1;
+      lin_tap(cx, p.W, p.sx, &x0, &x1, &a0, &a1);
+      lin_tap(cy, p.H, p.sy, &y0, &y1, &b0, &b1);
+      const uint8_t* r0 = p.frame + (size_t)y0 * p.W * 3;
+      const uint8_t* r1 = p.frame + (size_t)y1 * p.W * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int S0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+        const int S1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+        bgr[c] = ((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2) & 255;
+      }
+    }
+  }
+  // BGR -> RGB, /255 in float32 (BasePredictor.preprocess), then the network's 16-bit input type
+  const float r = __fdiv_rn((float)bgr[2], 255.f), gch = __fdiv_rn((float)bgr[1], 255.f), b = __fdiv_rn((float)bgr[0], 255.f);
+  *(u32x4*)((char*)p.out + (size_t)idx * 16) = u32x4{pack2<T>(r, gch), pack2<T>(b, 0.f), 0u, 0u};
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ydecode_kernel(const YDecodeP p) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= p.A) return;
+  const int lvl = a >= p.lvl_a0[2] ? 2 : (a >= p.lvl_a0[1] ? 1 : 0);
+  const int la = a - p.lvl_a0[lvl];
+  const int gy = la / p.lvl_w[lvl], gx = la - gy * p.lvl_w[lvl];
+  const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f, st = (float)p.lvl_stride[lvl];
+  const float* row = p.pred + (size_t)a * p.no;
+  float d[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float mx = row[s * 16];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, row[s * 16 + i]);
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = expf(row[s * 16 + i] - mx);
+      den += e;
+      num += e * (float)i;
+    }
+    d[s] = num / den;
+  }
+  // dist2bbox(xywh=True) * stride, then ops.xywh2xyxy (the order the reference pipeline applies them)
+  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  const float cx = __fmul_rn(__fmul_rn(__fadd_rn(x1, x2), 0.5f), st), cy = __fmul_rn(__fmul_rn(__fadd_rn(y1, y2), 0.5f), st);
+  const float w = __fmul_rn(__fsub_rn(x2, x1), st), h = __fmul_rn(__fsub_rn(y2, y1), st);
+  const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);
+  float* b = p.cand_box + (size_t)a * 4;
+  b[0] = __fsub_rn(cx, hw); b[1] = __fsub_rn(cy, hh); b[2] = __fadd_rn(cx, hw); b[3] = __fadd_rn(cy, hh);
+  float best = -1.f;
+  int bj = 0;
+  for (int j = 0; j < p.nc; ++j) {
+    const float s = 1.f / (1.f + expf(-row[64 + j]));
+    if (s > best) { best = s; bj = j; }
+  }
+  p.cand_conf[a] = best;
+  p.cand_cls[a] = bj;
+  if (best > p.conf) {
+    const int slot = atomicAdd(p.cand_count, 1);
+    if (slot < p.cand_cap) p.cand_list[slot] = a;
+  }
+}
+
+// ops.non_max_suppression (single label per box) + torchvision.ops.nms, one workgroup:
+// candidates sorted by (confidence descending, anchor ascending) -- torchvision's stable descending sort over
+// candidates that ultralytics leaves in anchor order -- then greedy suppression with
+// inter / (area_i + area_j - inter) > iou in round-to-nearest float32, boxes shifted by cls * max_wh.
+constexpr int kNmsCap = 4096;
+__global__ __launch_bounds__(1024) void ynms_kernel(const YNmsP p) {
+  __shared__ float sconf[kNmsCap];
+  __shared__ int sanc[kNmsCap];
+  __shared__ float sbox[kNmsCap][4];
+  __shared__ float sarea[kNmsCap];
+  __shared__ unsigned char dead[kNmsCap];
+  __shared__ int kept_n;
+  const int tid = threadIdx.x;
+  int n = min(min(*p.cand_count, p.cand_cap), kNmsCap);
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = tid; i < np2; i += 1024) {
+    if (i < n) { const int a = p.cand_list[i]; sanc[i] = a; sconf[i] = p.cand_conf[a]; }
+    else { sanc[i] = 0x7fffffff; sconf[i] = -1.f; }
+  }
+  if (tid == 0) kept_n = 0;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float ci = sconf[i], cl = sconf[l];
+          const int ai = sanc[i], al = sanc[l];
+          const bool i_first = ci > cl || (ci == cl && ai < al);      // desired order: i before l
+          const bool asc_block = (i & k) != 0;                         // this block sorts in the reverse order
+          if (i_first == asc_block) { sconf[i] = cl; sconf[l] = ci; sanc[i] = al; sanc[l] = ai; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += 1024) {
+    const int a = sanc[i];
+    const float off = __fmul_rn((float)p.cand_cls[a], p.max_wh);
+    const float* b = p.cand_box + (size_t)a * 4;
+    const float x1 = __fadd_rn(b[0], off), y1 = __fadd_rn(b[1], off), x2 = __fadd_rn(b[2], off), y2 = __fadd_rn(b[3], off);
+    sbox[i][0] = x1; sbox[i][1] = y1; sbox[i][2] = x2; sbox[i][3] = y2;
+    sarea[i] = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    dead[i] = 0;
+  }
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    if (dead[i]) continue;                              // uniform: every thread reads the same byte after the barrier
+    const int slot = kept_n;
+    __syncthreads();
+    if (tid == 0) {
+      const int a = sanc[i];
+      const float* b = p.cand_box + (size_t)a * 4;
+      float* d = p.det + (size_t)slot * 8;
+      const float fx[4] = {b[0], b[1], b[2], b[3]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float padv = (c & 1) ? p.pad_y : p.pad_x, lim = (c & 1) ? (float)p.frame_h : (float)p.frame_w;
+        const float v = __fdiv_rn(__fsub_rn(fx[c], padv), p.gain);
+        d[c] = fminf(fmaxf(v, 0.f), lim);
+        p.det_lb[slot * 4 + c] = fx[c];
+      }
+      d[4] = sconf[i]; d[5] = (float)p.cand_cls[a]; d[6] = (float)a; d[7] = 0.f;
+      p.det_anchor[slot] = a;
+      kept_n = slot + 1;
+    }
+    if (slot + 1 >= p.max_det) { __syncthreads(); break; }
+    const float ix1 = sbox[i][0], iy1 = sbox[i][1], ix2 = sbox[i][2], iy2 = sbox[i][3], ia = sarea[i];
+    for (int j = i + 1 + tid; j < n; j += 1024) {
+      if (dead[j]) continue;
+      const float w = fmaxf(0.f, __fsub_rn(fminf(ix2, sbox[j][2]), fmaxf(ix1, sbox[j][0])));
+      const float h = fmaxf(0.f, __fsub_rn(fminf(iy2, sbox[j][3]), fmaxf(iy1, sbox[j][1])));
+      const float inter = __fmul_rn(w, h);
+      const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ia, sarea[j]), inter));
+      if (ovr > p.iou) dead[j] = 1;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) *p.det_count = kept_n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ops.process_mask, step 1: masks = coef @ proto, cropped to the box at proto resolution
+template <typename T>
+__global__ __launch_bounds__(256) void ymask_low_kernel(const YMaskP p) {
+  const int i = blockIdx.y;
+  if (i >= *p.det_count) return;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.mh * p.mw) return;
+  const int y = pix / p.mw, x = pix - y * p.mw;
+  const float wr = (float)((double)p.mw / (double)p.iw), hr = (float)((double)p.mh / (double)p.ih);
+  const float* bl = p.det_lb + i * 4;
+  const float x1 = __fmul_rn(bl[0], wr), y1 = __fmul_rn(bl[1], hr), x2 = __fmul_rn(bl[2], wr), y2 = __fmul_rn(bl[3], hr);
+  float m = 0.f;
+  if ((float)x >= x1 && (float)x < x2 && (float)y >= y1 && (float)y < y2) {
+    const float* coef = p.pred + (size_t)p.det_anchor[i] * p.no + 64 + p.nc;
+    const char* pr = (const char*)p.proto + (size_t)pix * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 v = *(const u32x4*)(pr + c * 16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m += coef[c * 8 + 2 * k] * unpack_lo<T>(v[k]) + coef[c * 8 + 2 * k + 1] * unpack_hi<T>(v[k]);
+    }
+  }
+  p.low[(size_t)i * p.mh * p.mw + pix] = m;
+}
+
+// step 2 + get_bbox_mask's sum / clip / x255: bilinear upsample (F.interpolate, align_corners=False) of every cropped
+// mask to the letterboxed input, `> 0`, OR over instances -> 255 / 0
+__global__ __launch_bounds__(256) void ymask_merge_kernel(const YMaskP p) {
+  __shared__ float sb[300][4];
+  const int n = min(*p.det_count, p.max_det);
+  for (int i = threadIdx.x; i < n * 4; i += 256) sb[i >> 2][i & 3] = p.det_lb[i];
+  __syncthreads();
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.ih * p.iw) return;
+  const int Y = idx / p.iw, X = idx - Y * p.iw;
+  const float sch = (float)p.mh / (float)p.ih, scw = (float)p.mw / (float)p.iw;
+  float fy = __fsub_rn(__fmul_rn(sch, (float)Y + 0.5f), 0.5f), fx = __fsub_rn(__fmul_rn(scw, (float)X + 0.5f), 0.5f);
+  fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < p.mh - 1 ? 1 : 0), x1 = x0 + (x0 < p.mw - 1 ? 1 : 0);
+  const float ly1 = __fsub_rn(fy, (float)y0), lx1 = __fsub_rn(fx, (float)x0), ly0 = __fsub_rn(1.f, ly1), lx0 = __fsub_rn(1.f, lx1);
+  const float margin = 2.f * (float)p.iw / (float)p.mw;          // a cropped mask is zero further than one proto pixel outside its box
+  bool any = false;
+  for (int i = 0; i < n && !any; ++i) {
+    if ((float)X < sb[i][0] - margin || (float)X > sb[i][2] + margin || (float)Y < sb[i][1] - margin || (float)Y > sb[i][3] + margin) continue;
+    const float* L = p.low + (size_t)i * p.mh * p.mw;
+    const float a = L[y0 * p.mw + x0], b = L[y0 * p.mw + x1], c = L[y1 * p.mw + x0], d = L[y1 * p.mw + x1];
+    const float v = __fadd_rn(__fmul_rn(ly0, __fadd_rn(__fmul_rn(lx0, a), __fmul_rn(lx1, b))),
+                              __fmul_rn(ly1, __fadd_rn(__fmul_rn(lx0, c), __fmul_rn(lx1, d))));
+    any = v > 0.f;
+  }
+  p.merged[idx] = any ? 255 : 0;
+}
+
+// parity taps: a 16-bit / float32 / uint8 NHWC view -> float32 [C][H][W]
+template <typename T>
+__global__ __launch_bounds__(256) void yread_kernel(const void* src, int kind, int H, int W, int C, int ld, float* dst) {
+  const size_t total = (size_t)C * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const size_t r = i / W;
+    const int y = (int)(r % H), c = (int)(r / H);
+    const size_t s = ((size_t)y * W + x) * ld + c;
+    dst[i] = kind == 1 ? ((const float*)src)[s] : (kind == 2 ? (float)((const uint8_t*)src)[s] : to_f32<T>(((const T*)src)[s]));
+  }
+}
+
+}  // namespace
+
+extern "C" int flope_yread_launch(const void* src, int kind, int H, int W, int C, int ld, int dtype, float* dst, void* stream) {
+  const size_t total = (size_t)C * H * W;
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  if (dtype == 0) hipLaunchKernelGGL(yread_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, kind, H, W, C, ld, dst);
+  else hipLaunchKernelGGL(yread_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, kind, H, W, C, ld, dst);
+  return (int)hipGetLastError();
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------------------------------
+#define YDISPATCH(dt_, KERN, grid, block, lds, st, ...)                                                   \
+  do {                                                                                                    \
+    if ((dt_) == 0) hipLaunchKernelGGL(KERN<bf16_t>, grid, block, lds, st, __VA_ARGS__);                  \
+    else hipLaunchKernelGGL(KERN<f16_t>, grid, block, lds, st, __VA_ARGS__);                              \
+  } while (0)
+
+template <typename T>
+static void yconv_go(const YConvP& p, int nt, dim3 grid, hipStream_t st) {
+  const bool k3 = p.k == 3;
+#define GO(NT_)                                                                                            \
+  do {                                                                                                     \
+    if (k3) hipLaunchKernelGGL((yconv_kernel<T, NT_, true>), grid, dim3(256), 0, st, p);                   \
+    else hipLaunchKernelGGL((yconv_kernel<T, NT_, false>), grid, dim3(256), 0, st, p);                     \
+  } while (0)
+  if (nt == 1) GO(1); else if (nt == 2) GO(2); else GO(4);
+#undef GO
+}
+
+// nt = channel tiles of 16 per workgroup column (1, 2 or 4): rows of p->w / p->bias = ceil(Cout / (16 nt)) * 16 nt
+extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stream) {
+  if ((p->k != 1 && p->k != 3) || p->Cin % 8 || (nt != 1 && nt != 2 && nt != 4) || p->M < 1) return (int)hipErrorInvalidValue;
+  const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
+  if (p->out_mode == 2 && (p->dc % (16 * nt) || p->res)) return (int)hipErrorInvalidValue;
+  const dim3 grid((p->M + 127) / 128, (rows + 16 * nt - 1) / (16 * nt));
+  if (dtype == 0) yconv_go<bf16_t>(*p, nt, grid, (hipStream_t)stream); else yconv_go<f16_t>(*p, nt, grid, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream) {
+  if (p->C % 8) return (int)hipErrorInvalidValue;
+  const int total = p->H * p->W * (p->C / 8);
+  YDISPATCH(dtype, ydw_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream) {
+  if (p->C % 8) return (int)hipErrorInvalidValue;
+  const int total = p->H * p->W * (p->C / 8);
+  YDISPATCH(dtype, ypool_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_yup_launch(const YUpP* p, void* stream) {
+  if (p->C % 8) return (int)hipErrorInvalidValue;
+  const int total = 4 * p->H * p->W * (p->C / 8);
+  hipLaunchKernelGGL(yup_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_yattn_init() {
+  hipError_t e = hipFuncSetAttribute((const void*)yattn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return (int)e;
+}
+
+extern "C" int flope_yattn_launch(const YAttnP* p, int dtype, void* stream) {
+  const size_t lds = (size_t)16 * p->N * sizeof(float);
+  if (lds > 160 * 1024 || p->N < 1) return (int)hipErrorInvalidValue;      // N <= 2560 tokens (imgsz up to ~1600)
+  YDISPATCH(dtype, yattn_kernel, dim3((p->N + 15) / 16, p->heads), dim3(256), lds, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_yletter_launch(const YLetterP* p, int dtype, void* stream) {
+  YDISPATCH(dtype, yletter_kernel, dim3((p->h * p->w + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_ydecode_launch(const YDecodeP* p, void* stream) {
+  hipLaunchKernelGGL(ydecode_kernel, dim3((p->A + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_ynms_launch(const YNmsP* p, void* stream) {
+  if (p->max_det < 1 || p->max_det > 300) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(ynms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int flope_ymask_launch(const YMaskP* p, int dtype, void* stream) {
+  if (p->max_det < 1 || p->max_det > 300) return (int)hipErrorInvalidValue;
+  YDISPATCH(dtype, ymask_low_kernel, dim3((p->mh * p->mw + 255) / 256, p->max_det), dim3(256), 0, (hipStream_t)stream, *p);
+  hipLaunchKernelGGL(ymask_merge_kernel, dim3((p->ih * p->iw + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}

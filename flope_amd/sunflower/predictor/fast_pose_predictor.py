@@ -3,10 +3,13 @@
 -> Procrustes -> yaw-null -> Rt.  Everything after the detector runs on the GPU in one
 stream with a single device->host copy of the final ``[N,4,4]`` poses.
 
-Detector: the reference constructs ``ultralytics.YOLO(yolo_path)`` (:36).  ultralytics and
-its weights are third-party and absent here, so ``yolo_path`` may also be a callable
-``image -> (bbox int16 [N,4], mask uint8 [H,W])`` (the contract of ``get_bbox_mask``);
-a path string is handed to ultralytics if that package is importable.
+Detector: the reference constructs ``ultralytics.YOLO(yolo_path)`` (:36) and calls it per frame
+(:49).  Here ``yolo_path`` names the same network's weights -- a plain ``state_dict`` file of the
+ultralytics model (``tools/export_yolo_state_dict.py``), or the ``.pt`` itself where ultralytics
+is installed to unpickle it -- and the detector runs on this build's own kernels
+(``flope_amd/yolo.py``: letterbox, YOLO11-seg graph, DFL decode, NMS, mask assembly; C-ABI
+``flope_yolo_*``).  ``yolo_path`` may also be a callable ``image -> (bbox int16 [N,4], mask uint8
+[H,W])`` (the contract of ``get_bbox_mask``) to plug in any other detector.
 """
 from pathlib import Path
 
@@ -37,16 +40,19 @@ def select_boxes(boxes, frame_shape):
 
 
 def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_size=512, near=0.1, far=2.5,
-                          device=None):
-    """Shared tail of both predictors (fast_pose_predictor.py:65-156, pose_predictor.py:90-186)."""
+                          device=None, frame_d=None, mask_d=None):
+    """Shared tail of both predictors (fast_pose_predictor.py:65-156, pose_predictor.py:90-186).
+    frame_d / mask_d: the frame and the detector's mask when they are already on the device (the built-in detector)."""
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("flope_amd predictors run on HIP devices only")
     uv, sq_bb, good_bb = select_boxes(boxes, rgb.shape)
     if good_bb.shape[0] == 0:
         return None
-    frame_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
-    mask_d = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(dev)
+    if frame_d is None:
+        frame_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
+    if mask_d is None:
+        mask_d = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(dev)
     depth_np = np.ascontiguousarray(depth)
     if depth_np.dtype == np.uint16:
         depth_d = torch.from_numpy(depth_np.view(np.int16)).to(dev)        # bits travel unchanged
@@ -73,40 +79,40 @@ def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_s
 
 
 class FastPosePredictor:
-    def __init__(self, device: str, yolo_path, posenet_path: str, intrin_path: str, debug: bool = False):
+    def __init__(self, device: str, yolo_path, posenet_path: str, intrin_path: str, debug: bool = False,
+                 imgsz: int = None, yolo_dtype: str = "f16"):
         self.device = device
         self.debug = debug
         self.posenet = PoseResNet().to(device)
         self.posenet.load_state_dict(torch.load(posenet_path, weights_only=True))
         print(f"Model loaded: {Path(posenet_path).name}")
+        self.K, self.height, self.width = read_intrinsics_yaml_to_K_h_w(intrin_path)
         if callable(yolo_path):
             self.yolo = None
             self._detector = yolo_path
         else:
-            try:
-                from ultralytics import YOLO
-            except ImportError as exc:
-                raise ImportError("FastPosePredictor: ultralytics is not installed; pass a callable "
-                                  "image -> (bbox, mask) as yolo_path instead") from exc
-            self.yolo = YOLO(yolo_path).to(device)
-            self._detector = self._yolo_bbox_mask
-            print(f"YOLO loaded: {Path(yolo_path).name}")
-        self.K, self.height, self.width = read_intrinsics_yaml_to_K_h_w(intrin_path)
+            from flope_amd.yolo import YoloSeg, load_yolo_checkpoint
+            sd, ck_imgsz = load_yolo_checkpoint(str(yolo_path))
+            # ultralytics predicts at the size the checkpoint was trained with (the reference's is `yolo11nseg_1280.pt`, :177)
+            self.yolo = YoloSeg(int(self.height), int(self.width), int(imgsz or ck_imgsz or 1280), yolo_dtype, device=device)
+            self.yolo.load_state_dict(sd)
+            self._detector = self.yolo.get_bbox_mask
+            print(f"YOLO loaded: {Path(str(yolo_path)).name}")
         print("FastPosePredictor initialized!")
 
-    def _yolo_bbox_mask(self, image):
-        """fast_pose_predictor.py:44-57 on top of ultralytics (third-party, parity unpinned)."""
-        H, W, _ = image.shape
-        res = self.yolo(image)[0]
-        mask = _engine.merge_masks_resize(res.masks.data.to(self.device), H, W)      # sum/clip/x255/uint8/cv2.resize on the GPU
-        return res.boxes.xyxy.cpu().numpy().astype(np.int16), mask.cpu().numpy()
-
     def get_bbox_mask(self, image):
-        """-> (bbox int16 [N,4] xyxy, mask uint8 [H,W])"""
+        """-> (bbox int16 [N,4] xyxy, mask uint8 [H,W])   (fast_pose_predictor.py:44-57; no detection: empty bbox and
+        an all-zero mask, where the reference raises on `results[0].masks.data`)"""
         return self._detector(image)
 
     def get_flower_poses(self, rgb, depth):
         """rgb uint8 [H,W,3], depth uint16 [H,W] (millimetres) -> float64 [N,4,4] | None"""
+        if self.yolo is not None:                  # frame and mask stay on the device between the detector and the crops
+            det, count, mask_d, frame_d = self.yolo.detect_device(rgb)
+            n = int(count.item())
+            bb = det[:n, :4].cpu().numpy().astype(np.int16)           # :55-56
+            return poses_from_detections(self.posenet, rgb, depth, bb, None, self.K, depth_div=1000.0,
+                                         device=self.device, frame_d=frame_d, mask_d=mask_d)
         bb, mask = self.get_bbox_mask(rgb)
         return poses_from_detections(self.posenet, rgb, depth, bb, mask, self.K, depth_div=1000.0,
                                      device=self.device)

@@ -1,0 +1,153 @@
+"""YOLO11-seg detector on the GPU: Python owner of one ``flope_yolo_handle``.
+
+Replaces ``self.yolo = YOLO(yolo_path)`` / ``results = self.yolo(image)`` of the reference
+(``sunflower/predictor/fast_pose_predictor.py:36,44-57``; network = ultralytics 8.3.27, which the
+reference does not vendor).  PyTorch is plumbing (device buffers, the current stream); letterbox,
+the whole network, DFL decode, NMS and the mask assembly run in libflope_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {"f16": _lib.DT_F16, "bf16": _lib.DT_BF16}
+MAX_DET = 300
+
+
+def load_yolo_checkpoint(path: str):
+    """-> (state_dict of float tensors, imgsz or None).
+
+    Accepts a plain ``state_dict`` file (``torch.save(model.state_dict(), f)`` -- keys ``model.<i>. ...``; readable
+    with ``weights_only=True``; an optional ``imgsz`` entry carries the training size).  An ultralytics ``.pt`` is a
+    pickled model object: it can only be opened where ultralytics is installed, in which case its weights are taken
+    from it and still run on this build's kernels."""
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as exc:                      # a pickled ultralytics model: needs the package that defines its classes
+        try:
+            from ultralytics import YOLO
+        except ImportError:
+            raise RuntimeError(
+                f"{path}: not a plain state_dict file ({type(exc).__name__}) and ultralytics is not installed. Export the "
+                "weights once on a machine that has it: tools/export_yolo_state_dict.py <model.pt> <out.pth>") from exc
+        y = YOLO(path)
+        sd = {k: v.detach().float().cpu() for k, v in y.model.state_dict().items()}
+        imgsz = (getattr(y.model, "args", None) or {}).get("imgsz") if isinstance(getattr(y.model, "args", None), dict) else None
+        return sd, imgsz
+    if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
+        obj = {**obj["state_dict"], **({"imgsz": obj["imgsz"]} if "imgsz" in obj else {})}
+    if not isinstance(obj, dict) or "model.0.conv.weight" not in obj:
+        raise RuntimeError(f"{path}: expected a yolo11-seg state_dict (keys 'model.<i>. ...')")
+    imgsz = obj.get("imgsz")
+    imgsz = int(imgsz) if imgsz is not None else None
+    sd = {k: v for k, v in obj.items() if isinstance(v, torch.Tensor) and k != "imgsz"}
+    return sd, imgsz
+
+
+class YoloSeg:
+    def __init__(self, frame_h: int, frame_w: int, imgsz: int = 1280, dtype: str = "f16", device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("flope_amd: no HIP device visible; the product path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None
+                                   else torch.device(device).index or 0)
+        self.frame_h, self.frame_w, self.imgsz = int(frame_h), int(frame_w), int(imgsz)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.flope_yolo_create(self.device.index, self.frame_h, self.frame_w, self.imgsz, _DT[dtype], C.byref(h))
+        self._check(rc, None)
+        self.handle = h
+        ih, iw = C.c_int(), C.c_int()
+        self._check(self.lib.flope_yolo_input_size(self.handle, C.byref(ih), C.byref(iw)))
+        self.input_hw = (ih.value, iw.value)
+        self._det = torch.zeros((MAX_DET, 8), dtype=torch.float32, device=self.device)
+        self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._keep = None
+
+    def _check(self, rc, handle="self"):
+        if rc != 0:
+            h = self.handle if handle == "self" else handle
+            msg = self.lib.flope_yolo_last_error(h)
+            raise RuntimeError(f"flope_amd yolo error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.flope_yolo_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: dict) -> None:
+        items = [(k, v.detach().to("cpu", torch.float32).contiguous()) for k, v in sd.items()
+                 if isinstance(v, torch.Tensor) and v.is_floating_point() and not k.endswith("num_batches_tracked")]
+        n = len(items)
+        names = (C.c_char_p * n)(*[k.encode() for k, _ in items])
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, t in items])
+        ndims = (C.c_int * n)(*[t.dim() for _, t in items])
+        shape_arrs = [(C.c_int64 * max(t.dim(), 1))(*t.shape) for _, t in items]
+        shapes = (C.c_void_p * n)(*[C.cast(a, C.c_void_p).value for a in shape_arrs])
+        with torch.cuda.device(self.device):
+            self._check(self.lib.flope_yolo_load_weights(self.handle, n, names, ptrs, ndims, shapes))
+
+    def _frame(self, frame) -> torch.Tensor:
+        if isinstance(frame, np.ndarray):
+            frame = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))
+        if frame.dtype != torch.uint8 or tuple(frame.shape) != (self.frame_h, self.frame_w, 3):
+            raise ValueError(f"expected a uint8 BGR frame [{self.frame_h},{self.frame_w},3], got {frame.dtype} {tuple(frame.shape)}")
+        return frame.to(self.device).contiguous()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self, frame) -> None:
+        """letterbox + network only (parity taps via read_tensor)."""
+        f = self._frame(frame)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.flope_yolo_forward(self.handle, f.data_ptr(), self._stream()))
+        self._keep = f
+
+    def detect_device(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET):
+        """-> (det float32 [max_det,8] on the device, count int32 [1] on the device, mask uint8 [H,W] on the device, frame
+        tensor on the device).  Nothing is synchronised."""
+        f = self._frame(frame)
+        mask = torch.empty((self.frame_h, self.frame_w), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.flope_yolo_detect(self.handle, f.data_ptr(), float(conf), float(iou), int(max_det),
+                                                   self._det.data_ptr(), self._count.data_ptr(), mask.data_ptr(), self._stream()))
+        self._keep = f
+        return self._det, self._count, mask, f
+
+    def detect(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET):
+        """-> (boxes float32 [n,4] frame xyxy, conf [n], cls [n], anchor [n], mask uint8 [H,W]) as numpy arrays."""
+        det, count, mask, _ = self.detect_device(frame, conf, iou, max_det)
+        n = int(count.item())
+        d = det[:n].cpu().numpy()
+        return d[:, :4].copy(), d[:, 4].copy(), d[:, 5].astype(np.int64), d[:, 6].astype(np.int64), mask.cpu().numpy()
+
+    def get_bbox_mask(self, image, conf: float = 0.25, iou: float = 0.7):
+        """fast_pose_predictor.py:44-57: -> (bbox int16 [N,4] xyxy, mask uint8 [H,W])."""
+        boxes, _, _, _, mask = self.detect(image, conf, iou)
+        return boxes.astype(np.int16), mask
+
+    def read_tensor(self, name: str) -> torch.Tensor:
+        dims = (C.c_int64 * 3)()
+        self._check(self.lib.flope_yolo_read_tensor(self.handle, name.encode(), None, dims, None))     # size query
+        c, h, w = (int(d) for d in dims)
+        buf = torch.empty((c, h, w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.flope_yolo_read_tensor(self.handle, name.encode(), buf.data_ptr(), dims, self._stream()))
+        return buf
+
+    def flops(self) -> float:
+        return float(self.lib.flope_yolo_flops(self.handle))
+
+    def launches(self) -> int:
+        return int(self.lib.flope_yolo_launches(self.handle))

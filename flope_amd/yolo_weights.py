@@ -17,6 +17,9 @@ import math
 import torch
 
 BN_KEYS = ("weight", "bias", "running_mean", "running_var")
+# BatchNorm gamma multipliers that keep the random-init activations O(1) through the neck (measured with the CPU oracle)
+_DAMPED = {"model.9.cv2": 0.45, "model.10.cv2": 0.6, "model.13.cv2": 0.6, "model.16.cv2": 0.8, "model.19.cv2": 0.7,
+           "model.22.cv2": 0.7, "model.8.cv2": 0.8, "model.6.cv2": 0.9}
 
 
 def conv_specs(widths=(16, 32, 64, 128, 256), nc: int = 1, nm: int = 32):
@@ -98,7 +101,7 @@ def conv_specs(widths=(16, 32, 64, 128, 256), nc: int = 1, nm: int = 32):
     return out
 
 
-def synthetic_yolo_state_dict(seed: int = 0, nc: int = 1, cls_bias: float = -4.0) -> dict:
+def synthetic_yolo_state_dict(seed: int = 0, nc: int = 1, cls_bias: float = -4.5) -> dict:
     """Seeded random-init yolo11n-seg ``state_dict`` (CPU generator: identical on every machine).
     He-scaled convolutions, non-trivial BatchNorm statistics, and a class-head bias that lets a small
     fraction of the anchors pass the default 0.25 confidence threshold on a noise frame."""
@@ -113,6 +116,8 @@ def synthetic_yolo_state_dict(seed: int = 0, nc: int = 1, cls_bias: float = -4.0
             linear = any(p.endswith(t) for t in (".attn.qkv", ".attn.proj", ".attn.pe", ".ffn.1"))
             closing = p.endswith(".cv2") and ".m." in p.rsplit(".cv2", 1)[0][-6:]
             gain, gamma = (1.0, 0.5) if linear else ((2.0, 0.5) if closing else (2.0, 1.0))
+            if p in _DAMPED:                        # block outputs fed by wide concatenations of correlated maps
+                gamma *= _DAMPED[p]
             sd[p + ".conv.weight"] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(gain / fan_in)
             sd[p + ".bn.weight"] = (0.9 + 0.4 * torch.rand(cout, generator=g)) * gamma
             sd[p + ".bn.bias"] = 0.1 * torch.randn(cout, generator=g)
@@ -122,9 +127,9 @@ def synthetic_yolo_state_dict(seed: int = 0, nc: int = 1, cls_bias: float = -4.0
         elif kind == "plain":
             sd[p + ".weight"] = torch.randn(cout, cin, 1, 1, generator=g) * math.sqrt(1.0 / fan_in)
             sd[p + ".bias"] = 0.1 * torch.randn(cout, generator=g)
-            if ".cv3." in p:
+            if ".cv3." in p:                      # class logits ~ N(cls_bias, ~1.5^2): a few percent of the anchors pass 0.25
                 sd[p + ".bias"] = torch.full((cout,), float(cls_bias))
-                sd[p + ".weight"] = sd[p + ".weight"] * 2.0
+                sd[p + ".weight"] = sd[p + ".weight"] * 3.0
         else:                                       # ConvTranspose2d weight [cin, cout, 2, 2]
             sd[p + ".weight"] = torch.randn(cin, cout, 2, 2, generator=g) * math.sqrt(2.0 / cin)
             sd[p + ".bias"] = 0.1 * torch.randn(cout, generator=g)

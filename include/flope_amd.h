@@ -197,6 +197,41 @@ int flope_tf_set_option(flope_tf_handle h, const char* name, int value);
 /* algorithmic FLOPs of one forward (2*MAC: linears + QK^T + PV) */
 double flope_tf_forward_flops(flope_tf_handle h, int batch, int seq_len);
 
+/* ---- YOLO11-seg detector front end ---------------------------------------------------
+ * Replaces `self.yolo = YOLO(yolo_path)` (sunflower/predictor/fast_pose_predictor.py:36) and the
+ * `results = self.yolo(image)` + mask / box post-processing of `get_bbox_mask` (:44-57).  The network and
+ * its pre/post-processing are those of ultralytics 8.3.27 (environment.yml:231; not vendored by the reference):
+ * LetterBox(imgsz, auto, stride 32) + BGR->RGB + /255 -> yolo11-seg graph (Conv+BN+SiLU, C3k2, SPPF, C2PSA,
+ * upsample/concat neck, Segment head) -> DFL decode -> NMS -> coef.proto masks cropped, upsampled, > 0.
+ * One handle = one device, one frame size.  dtype FLOPE_DT_F16 / FLOPE_DT_BF16 (16-bit maps, fp32 accumulation,
+ * fp32 head outputs / decode / NMS). */
+typedef struct flope_yolo* flope_yolo_handle;
+int flope_yolo_create(int device_id, int frame_h, int frame_w, int imgsz, int dtype, flope_yolo_handle* out);
+int flope_yolo_destroy(flope_yolo_handle h);
+const char* flope_yolo_last_error(flope_yolo_handle h);
+/* letterboxed network input size for this frame size (multiples of 32) */
+int flope_yolo_input_size(flope_yolo_handle h, int* in_h, int* in_w);
+/* the ultralytics model's state_dict (`model.<i>. ...` names, host fp32): builds the graph from the key set and the
+ * tensor shapes, folds BatchNorm(eps 1e-3), packs for MFMA, allocates every intermediate map.  Once per handle. */
+int flope_yolo_load_weights(flope_yolo_handle h, int n, const char* const* names,
+                            const float* const* host_ptrs, const int* ndims, const int64_t* const* shapes);
+/* `results = self.yolo(image)` + get_bbox_mask's post-processing.  frame_dev: uint8 BGR [H,W,3] (a cv2 image).
+ * conf / iou / max_det: ultralytics predict defaults are 0.25 / 0.7 / 300 (max_det <= 300).
+ * det_dev float32 [max_det,8]: rows = xyxy in frame pixels (ops.scale_boxes, clipped; the reference casts them to
+ * int16), confidence, class, anchor index, 0 -- in NMS order; count_dev int32 [1]; mask_dev uint8 [H,W] = the summed /
+ * clipped / x255 instance masks resized to the frame with cv2's 8-bit INTER_LINEAR (fast_pose_predictor.py:50-54). */
+int flope_yolo_detect(flope_yolo_handle h, const uint8_t* frame_dev, float conf, float iou, int max_det,
+                      float* det_dev, int32_t* count_dev, uint8_t* mask_dev, void* stream);
+/* network only (parity tests): letterbox + every layer, no post-processing */
+int flope_yolo_forward(flope_yolo_handle h, const uint8_t* frame_dev, void* stream);
+/* copy one map of the LAST forward to float32 [C,H,W]: "input", graph outputs "0".."22" (yaml indices of Conv / C3k2 /
+ * SPPF / C2PSA modules), "box0..2" / "cls0..2" / "coef0..2" (Segment head rows per level), "proto", "proto_up",
+ * "mask_lb" (merged mask at the letterboxed size, after flope_yolo_detect).  dims_out[3] = {C,H,W}; dst_dev NULL = size
+ * query only. */
+int flope_yolo_read_tensor(flope_yolo_handle h, const char* name, float* dst_dev, int64_t* dims_out, void* stream);
+double flope_yolo_flops(flope_yolo_handle h);      /* 2*MAC of one forward (convs + attention) */
+int flope_yolo_launches(flope_yolo_handle h);      /* kernel launches per flope_yolo_detect */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,192 @@
+"""GPU parity of the YOLO11-seg detector front end (C-ABI flope_yolo_*) against oracle/yolo_ref.py.
+Tolerances: 16-bit maps (f16) against the fp32 oracle: rel-L2 <= 1e-2 per graph output (rounding accumulates over ~25
+fused layers); float32 head rows <= 1e-2 rel; NMS indices bit-exact given the same head rows; boxes <= 1e-3 px given the
+same rows; merged mask: identical except sign flips of ~0 values (< 0.02 % of pixels); uint8 resize: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_ref as P
+from oracle import yolo_ref as Y
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "13", "16", "17", "19", "20", "22"]
+
+
+@pytest.fixture(scope="module")
+def ysd():
+    from flope_amd.yolo_weights import synthetic_yolo_state_dict
+    return synthetic_yolo_state_dict(0)
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def _engine(ysd, H, W, imgsz, dtype="f16"):
+    from flope_amd.yolo import YoloSeg
+    y = YoloSeg(H, W, imgsz, dtype)
+    y.load_state_dict(ysd)
+    return y
+
+
+@pytest.mark.parametrize("H,W,imgsz,dtype,tol", [(1080, 1920, 1280, "f16", 1e-2), (360, 640, 640, "f16", 1e-2), (300, 500, 320, "f16", 1e-2),
+                                                 (250, 333, 640, "bf16", 8e-2)])
+def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol):
+    from flope_amd.yolo_weights import synthetic_frame
+    img = synthetic_frame(3, H, W)
+    y = _engine(ysd, H, W, imgsz, dtype)
+    y.forward(img)
+    x = Y.preprocess(img, imgsz)
+    assert tuple(x.shape[2:]) == y.input_hw
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    got_in = y.read_tensor("input").cpu()
+    assert torch.equal(got_in[:3], x[0].to(tdt).float()) and not got_in[3:].any()      # letterbox + BGR->RGB + /255: exact
+    o = Y.forward_layers(ysd, x)
+    for name in LAYERS:
+        got = y.read_tensor(name).cpu()
+        ref = o[int(name)][0]
+        assert got.shape == ref.shape, name
+        assert _rel(got, ref) <= tol, (name, _rel(got, ref))
+    for name in ["proto_up", "proto"] + [f"{k}{i}" for i in range(3) for k in ("box", "cls", "coef")]:
+        got, ref = y.read_tensor(name).cpu(), o[name][0]
+        assert got.shape == ref.shape, name
+        assert _rel(got, ref) <= 2 * tol, (name, _rel(got, ref))
+    y.close()
+
+
+def _head_rows(y):
+    """the device's own float32 head rows as the oracle's `o` dict"""
+    o = {}
+    for i in range(3):
+        for k in ("box", "cls", "coef"):
+            o[f"{k}{i}"] = y.read_tensor(f"{k}{i}").cpu()[None]
+    return o
+
+
+@pytest.mark.parametrize("H,W,imgsz,conf,iou,max_det", [(1080, 1920, 1280, 0.25, 0.7, 300), (1080, 1920, 1280, 0.05, 0.45, 300),
+                                                        (1080, 1920, 1280, 0.02, 0.7, 17), (360, 640, 640, 0.25, 0.7, 300),
+                                                        (360, 640, 640, 0.9999, 0.7, 300)])
+def test_decode_nms_boxes_bit_exact_given_the_head_rows(ysd, H, W, imgsz, conf, iou, max_det):
+    """Detect._inference + ops.non_max_suppression + ops.scale_boxes on the device against the numpy restatement fed
+    with the SAME float32 head rows: kept anchors and their order identical, boxes / scores to float32 round-off."""
+    from flope_amd.yolo_weights import synthetic_frame
+    img = synthetic_frame(4, H, W)
+    y = _engine(ysd, H, W, imgsz)
+    boxes, sc, cls, anchor, mask = y.detect(img, conf, iou, max_det)
+    pred = Y.decode(_head_rows(y)).numpy()
+    det, idx = Y.non_max_suppression(pred, 1, conf, iou, max_det)
+    assert anchor.tolist() == idx.tolist(), (len(anchor), len(idx))
+    if conf < 0.9:
+        assert len(idx) >= (10 if max_det > 17 else 17)
+    else:
+        assert len(idx) == 0 and not mask.any()
+    if len(idx):
+        np.testing.assert_allclose(sc, det[:, 4], rtol=2e-6)
+        ref_boxes = Y.scale_boxes(y.input_hw, det[:, :4], img.shape)
+        np.testing.assert_allclose(boxes, ref_boxes, atol=2e-3)
+        assert (cls == 0).all() and (np.diff(sc) <= 0).all()
+    y.close()
+
+
+def test_masks_vs_oracle_given_the_head_rows(ysd):
+    """ops.process_mask + get_bbox_mask's sum / clip / x255 / cv2.resize on the device, fed to the oracle from the
+    device's own proto map, coefficients and boxes."""
+    from flope_amd.yolo_weights import synthetic_frame
+    H, W, imgsz = 1080, 1920, 1280
+    img = synthetic_frame(5, H, W)
+    y = _engine(ysd, H, W, imgsz)
+    boxes, sc, cls, anchor, mask = y.detect(img)
+    o = _head_rows(y)
+    pred = Y.decode(o).numpy()
+    det, idx = Y.non_max_suppression(pred, 1)
+    assert anchor.tolist() == idx.tolist() and len(idx) >= 5
+    proto = y.read_tensor("proto").cpu()
+    ref_masks = Y.process_mask(proto, det[:, 6:], det[:, :4], y.input_hw).numpy()
+    ref_lb = (np.clip(ref_masks.sum(0), 0, 1) * 255).astype(np.uint8)
+    got_lb = y.read_tensor("mask_lb").cpu().numpy()[0].astype(np.uint8)
+    assert got_lb.shape == ref_lb.shape and set(np.unique(got_lb)) <= {0, 255}
+    assert (got_lb != ref_lb).mean() < 2e-4, float((got_lb != ref_lb).mean())
+    assert 0.02 < (got_lb > 0).mean() < 0.98
+    assert np.array_equal(mask, P.resize_linear_u8(got_lb, (W, H)))          # cv2.resize((W,H)) of the device's own merged mask
+    y.close()
+
+
+def test_detector_end_to_end_vs_fp32_oracle(ysd):
+    """frame -> get_bbox_mask on the device (16-bit network) against the full fp32 CPU oracle."""
+    from flope_amd.yolo_weights import synthetic_frame
+    H, W = 1080, 1920
+    img = synthetic_frame(6, H, W)
+    y = _engine(ysd, H, W, 1280)
+    bb, mask = y.get_bbox_mask(img)
+    rb, rmask = Y.get_bbox_mask(ysd, img, 1280)
+    assert bb.dtype == np.int16 and mask.dtype == np.uint8 and mask.shape == (H, W)
+    rboxes, rconf, _ = Y.detect(ysd, img, 1280)
+    boxes, conf, _, _, _ = y.detect(img)
+
+    def iou(a, b):
+        iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0])); ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
+        u = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - iw * ih
+        return iw * ih / u if u > 0 else 0.0
+    # every confident detection of either side has a partner (a candidate within 0.01 of the threshold may flip)
+    for A, ca, B in ((rboxes, rconf, boxes), (boxes, conf, rboxes)):
+        for b_, c_ in zip(A, ca):
+            if c_ > 0.27:
+                assert max(iou(b_, o_) for o_ in B) > 0.9, (b_, c_)
+    inter = np.logical_and(mask > 127, rmask > 127).sum(); union = np.logical_or(mask > 127, rmask > 127).sum()
+    assert union > 0 and inter / union > 0.97, inter / union
+    y.close()
+
+
+def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path):
+    """BASELINE configs[2] end to end: FastPosePredictor(device, yolo_path=<state_dict file>, posenet_path, intrin_path)
+    on a 1080p frame -- detector, crops, PoseResNet, Procrustes, depth lift, all on the device."""
+    import yaml
+    from flope_amd.yolo_weights import synthetic_frame
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor
+    H, W = 1080, 1920
+    img = synthetic_frame(7, H, W)
+    rng = np.random.default_rng(7)
+    depth = (400 + rng.normal(0, 4, (H, W))).astype(np.uint16)
+    yolo_f, ckpt, intr = tmp_path / "yolo11n_seg.pth", tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save({**ysd, "imgsz": torch.tensor(1280)}, yolo_f)
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=1400.0, fy=1400.0, cx=W / 2, cy=H / 2, h=H, w=W)))
+    from oracle import posenet_ref as O
+    pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr))
+    bb, mask = pred.get_bbox_mask(img)
+    assert bb.dtype == np.int16 and bb.shape[0] >= 5 and mask.shape == (H, W)
+    Rt = pred.get_flower_poses(img, depth)
+    K = np.array([[1400.0, 0, W / 2], [0, 1400.0, H / 2], [0, 0, 1]])
+    ref = P.get_flower_poses(lambda b: O.forward(state_dict, b), O.procrustes_to_rotmat, img, depth, bb, mask, K)
+    assert Rt is not None and Rt.shape == ref.shape and Rt.shape[0] >= 3
+    assert np.abs(Rt[:, :3, :3] - ref[:, :3, :3]).max() <= 1e-3
+    assert np.linalg.norm(Rt[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
+    # and the detector half against the fp32 oracle: same number of boxes within a pixel, or a marginal candidate differs
+    rb, rmask = Y.get_bbox_mask(ysd, img, 1280)
+    if rb.shape == bb.shape:
+        assert np.abs(rb.astype(int) - bb.astype(int)).max() <= 2
+    assert (np.logical_xor(mask > 127, rmask > 127)).mean() < 0.02
+
+
+def test_yolo_error_paths(ysd):
+    from flope_amd.yolo import YoloSeg
+    with pytest.raises(RuntimeError, match="imgsz"):
+        YoloSeg(480, 640, 333)
+    y = YoloSeg(480, 640, 640)
+    with pytest.raises(RuntimeError, match="before flope_yolo_load_weights"):
+        y.forward(np.zeros((480, 640, 3), np.uint8))
+    bad = {k: v for k, v in ysd.items() if not k.startswith("model.8.")}
+    with pytest.raises(RuntimeError, match="missing"):
+        y.load_state_dict(bad)
+    y.close()
+    y = YoloSeg(480, 640, 640)
+    y.load_state_dict(ysd)
+    with pytest.raises(ValueError, match="uint8 BGR frame"):
+        y.forward(np.zeros((481, 640, 3), np.uint8))
+    with pytest.raises(RuntimeError, match="max_det"):
+        y.detect(np.zeros((480, 640, 3), np.uint8), max_det=301)
+    with pytest.raises(RuntimeError, match="already loaded"):
+        y.load_state_dict(ysd)
+    y.close()
