@@ -26,14 +26,19 @@ __device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); 
 template <typename T> __device__ __forceinline__ float ld16(const void* p) { return to_f32<T>(*(const T*)p); }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int NT, bool K3>
+// SPLITK: the four waves of a workgroup share ONE 32-pixel tile and each walks a quarter of the K steps; partial sums
+// are added in wave order through LDS (deterministic).  Used for the small maps (<= 16 k pixels), where a layer is a
+// handful of workgroups and its serial K loop -- one L2 / Infinity-Cache round trip per step -- IS its latency.
+// Every variant keeps PD = 4 K steps of operand fragments in flight (the first version prefetched one step: 0.7 us per
+// step on the 23 x 40 maps, 50 us for a 72-step layer).
+template <typename T, int NT, bool K3, bool SPLITK>
 __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
   typedef typename Elem<T>::frag frag;
-  constexpr int MTW = 2, CB = 16 * NT;               // pixel tiles per wave, channels per block
+  constexpr int MTW = 2, CB = 16 * NT, PD = 4;       // pixel tiles per wave, channels per block, pipeline depth
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c16 = lane & 15;
-  const int m_base = (blockIdx.x * 4 + wave) * (16 * MTW);
-  if (m_base >= p.M) return;
+  const int m_base = SPLITK ? blockIdx.x * (16 * MTW) : (blockIdx.x * 4 + wave) * (16 * MTW);
+  if (!SPLITK && m_base >= p.M) return;
   const int nblk = blockIdx.y;
   const int pad = K3 ? 1 : 0;
   const size_t Kp2 = (size_t)p.ksteps * 64;          // bytes per weight row
@@ -51,10 +56,12 @@ __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
   const char* const wrow = (const char*)p.w + (size_t)(nblk * CB + c16) * Kp2 + g * 16;
   const char* const in = (const char*)p.in;
   const char* const zero = (const char*)p.zero;
+  const int ks0 = SPLITK ? (wave * p.ksteps) >> 2 : 0, ks1 = SPLITK ? ((wave + 1) * p.ksteps) >> 2 : p.ksteps;
   f32x4 acc[MTW][NT];
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
-    const f32x4 b = *(const f32x4*)(p.bias + nblk * CB + ct * 16 + g * 4);     // bias is stored in packed-row order
+    f32x4 b = *(const f32x4*)(p.bias + nblk * CB + ct * 16 + g * 4);           // bias is stored in packed-row order
+    if (SPLITK && wave != 0) b = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pt = 0; pt < MTW; ++pt) acc[pt][ct] = b;
   }
@@ -82,21 +89,46 @@ __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
       xf[pt] = *(const frag*)a;
     }
   };
-  frag wf[2][NT], xf[2][MTW];
-  load_step(0, wf[0], xf[0]);
-  for (int ks = 0; ks < p.ksteps; ks += 2) {          // two steps per trip: both register sets are compile-time indexed
-    if (ks + 1 < p.ksteps) load_step(ks + 1, wf[1], xf[1]);
+  // software pipeline, PD steps deep: loads are unconditional (steps past the end re-read the last one) so that the
+  // compiler's counted s_waitcnt vmcnt(N) never degenerates into a full drain at a control-flow join
+  frag wf[PD][NT], xf[PD][MTW];
+  const int klast = ks1 - 1;
+  if (ks0 < ks1) {
 #pragma unroll
-    for (int pt = 0; pt < MTW; ++pt)
+    for (int s_ = 0; s_ < PD; ++s_) load_step(min(ks0 + s_, klast), wf[s_], xf[s_]);
+    for (int ks = ks0; ks < ks1; ks += PD) {
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[0][ct], xf[0][pt], acc[pt][ct]);
-    if (ks + 1 < p.ksteps) {
-      if (ks + 2 < p.ksteps) load_step(ks + 2, wf[0], xf[0]);
+      for (int s_ = 0; s_ < PD; ++s_) {
+        if (ks + s_ < ks1) {
+#pragma unroll
+          for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[s_][ct], xf[s_][pt], acc[pt][ct]);
+        }
+        load_step(min(ks + s_ + PD, klast), wf[s_], xf[s_]);
+      }
+    }
+  }
+  if constexpr (SPLITK) {
+    __shared__ float red[3][MTW * NT * 4][64];
+    if (wave != 0) {
 #pragma unroll
       for (int pt = 0; pt < MTW; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[1][ct], xf[1][pt], acc[pt][ct]);
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) red[wave - 1][(pt * NT + ct) * 4 + q][lane] = acc[pt][ct][q];
     }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[pt][ct][q] += red[w][(pt * NT + ct) * 4 + q][lane];
   }
   // ---- epilogue: this lane = pixel c16 of each tile x channels ch0 .. ch0 + 4 NT - 1
   const int ch0 = nblk * CB + g * 4 * NT;
@@ -287,6 +319,87 @@ __global__ __launch_bounds__(256) void yattn_kernel(const YAttnP p) {
     const float inv = 1.f / l;
     *(u32x2*)((char*)p.out + ((size_t)qi * p.ldo + h * 64 + kl * 4) * 2) =
         u32x2{pack2<T>(a0 * inv, a1 * inv), pack2<T>(a2 * inv, a3 * inv)};
+  }
+}
+
+// MFMA form for N <= 1280 tokens (imgsz 1280 at 16:9 gives 23 x 40 = 920).  One workgroup = 64 queries of one head.
+//   * V^T of the head lives in LDS ([64 dims][N keys], 16-bit): the keys of every 32-key block are stored in the order
+//     4g..4g+3, 16+4g..16+4g+3 (g = 0..3), which is exactly the order in which a lane of the S^T accumulators holds
+//     its scores, so P^T feeds the second MFMA straight from registers and the V^T fragment is one ds_read_b128;
+//   * S^T[key][query] = K . Q^T on v_mfma_16x16x32 (K rows and the query rows are 16-byte global loads: key_dim = 32
+//     = one MFMA step); online softmax in fp32 in the accumulator layout (a query is a column: per-lane scalars, the
+//     maximum crosses the four row groups with two shuffles); O^T[dim][query] += V^T . P^T.
+template <typename T>
+__global__ __launch_bounds__(256) void yattn_mfma_kernel(const YAttnP p) {
+  typedef typename Elem<T>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char vt[];
+  const int NB = (p.N + 31) >> 5, rowB = NB * 64 + 16;      // odd number of 16-byte slots per row: conflict-free column reads
+  const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const char* base = (const char*)p.qkv + (size_t)h * 256;
+  const size_t ldB = (size_t)p.ld * 2;
+  for (int i = tid; i < NB * 32 * 8; i += 256) {
+    const int j = i >> 3, c = i & 7;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (j < p.N) v = *(const u32x4*)(base + (size_t)j * ldB + 128 + c * 16);
+    const int jj = j & 31;
+    const int pos = jj < 16 ? 8 * (jj >> 2) + (jj & 3) : 8 * ((jj - 16) >> 2) + 4 + (jj & 3);
+    char* d = vt + (size_t)(8 * c) * rowB + ((j & ~31) + pos) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *(unsigned short*)(d + (size_t)(2 * e) * rowB) = (unsigned short)(v[e] & 0xffffu);
+      *(unsigned short*)(d + (size_t)(2 * e + 1) * rowB) = (unsigned short)(v[e] >> 16);
+    }
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  if (q0 >= p.N) return;
+  const int qi = min(q0 + c16, p.N - 1);
+  const frag qf = *(const frag*)(base + (size_t)qi * ldB + g * 16);
+  f32x4 o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int blk = 0; blk < NB; ++blk) {
+    const int kbase = blk * 32;
+    const frag ka = *(const frag*)(base + (size_t)min(kbase + c16, p.N - 1) * ldB + 64 + g * 16);
+    const frag kb = *(const frag*)(base + (size_t)min(kbase + 16 + c16, p.N - 1) * ldB + 64 + g * 16);
+    f32x4 s0 = Elem<T>::mfma(ka, qf, z4), s1 = Elem<T>::mfma(kb, qf, z4);    // s0[r]: key kbase + 4g + r, query q0 + c16
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0[r] = kbase + 4 * g + r < p.N ? s0[r] * p.scale : -3.0e38f;
+      s1[r] = kbase + 16 + 4 * g + r < p.N ? s1[r] * p.scale : -3.0e38f;
+      mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx), alpha = __expf(m - mn);
+    float pr[8], ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = __expf(s0[r] - mn); pr[4 + r] = __expf(s1[r] - mn); }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ps += pr[r];
+    l = l * alpha + ps;
+    m = mn;
+    const u32x4 pw = u32x4{pack2<T>(pr[0], pr[1]), pack2<T>(pr[2], pr[3]), pack2<T>(pr[4], pr[5]), pack2<T>(pr[6], pr[7])};
+    const frag pf = __builtin_bit_cast(frag, pw);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const frag vf = *(const frag*)(vt + (size_t)(t * 16 + c16) * rowB + (kbase + 8 * g) * 2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[t][r] *= alpha;
+      o[t] = Elem<T>::mfma(vf, pf, o[t]);                                      // D[dim t*16 + 4g + r][query c16]
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (q0 + c16 < p.N) {
+    const float inv = 1.f / l;
+    char* op = (char*)p.out + ((size_t)(q0 + c16) * p.ldo + h * 64 + 4 * g) * 2;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *(u32x2*)(op + t * 32) = u32x2{pack2<T>(o[t][0] * inv, o[t][1] * inv), pack2<T>(o[t][2] * inv, o[t][3] * inv)};
   }
 }
 
@@ -547,12 +660,14 @@ extern "C" int flope_yread_launch(const void* src, int kind, int H, int W, int C
   } while (0)
 
 template <typename T>
-static void yconv_go(const YConvP& p, int nt, dim3 grid, hipStream_t st) {
+static void yconv_go(const YConvP& p, int nt, bool splitk, dim3 grid, hipStream_t st) {
   const bool k3 = p.k == 3;
 #define GO(NT_)                                                                                            \
   do {                                                                                                     \
-    if (k3) hipLaunchKernelGGL((yconv_kernel<T, NT_, true>), grid, dim3(256), 0, st, p);                   \
-    else hipLaunchKernelGGL((yconv_kernel<T, NT_, false>), grid, dim3(256), 0, st, p);                     \
+    if (k3 && splitk) hipLaunchKernelGGL((yconv_kernel<T, NT_, true, true>), grid, dim3(256), 0, st, p);   \
+    else if (k3) hipLaunchKernelGGL((yconv_kernel<T, NT_, true, false>), grid, dim3(256), 0, st, p);       \
+    else if (splitk) hipLaunchKernelGGL((yconv_kernel<T, NT_, false, true>), grid, dim3(256), 0, st, p);   \
+    else hipLaunchKernelGGL((yconv_kernel<T, NT_, false, false>), grid, dim3(256), 0, st, p);              \
   } while (0)
   if (nt == 1) GO(1); else if (nt == 2) GO(2); else GO(4);
 #undef GO
@@ -563,8 +678,9 @@ extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stre
   if ((p->k != 1 && p->k != 3) || p->Cin % 8 || (nt != 1 && nt != 2 && nt != 4) || p->M < 1) return (int)hipErrorInvalidValue;
   const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
   if (p->out_mode == 2 && (p->dc % (16 * nt) || p->res)) return (int)hipErrorInvalidValue;
-  const dim3 grid((p->M + 127) / 128, (rows + 16 * nt - 1) / (16 * nt));
-  if (dtype == 0) yconv_go<bf16_t>(*p, nt, grid, (hipStream_t)stream); else yconv_go<f16_t>(*p, nt, grid, (hipStream_t)stream);
+  const bool splitk = p->M <= 16384 && p->ksteps >= 8;       // small map, long K: one tile per workgroup, K over its 4 waves
+  const dim3 grid(splitk ? (p->M + 31) / 32 : (p->M + 127) / 128, (rows + 16 * nt - 1) / (16 * nt));
+  if (dtype == 0) yconv_go<bf16_t>(*p, nt, splitk, grid, (hipStream_t)stream); else yconv_go<f16_t>(*p, nt, splitk, grid, (hipStream_t)stream);
   return (int)hipGetLastError();
 }
 
@@ -592,12 +708,22 @@ extern "C" int flope_yup_launch(const YUpP* p, void* stream) {
 extern "C" int flope_yattn_init() {
   hipError_t e = hipFuncSetAttribute((const void*)yattn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return (int)e;
 }
 
-extern "C" int flope_yattn_launch(const YAttnP* p, int dtype, void* stream) {
+// variant: 0 = automatic (MFMA kernel while the head's V^T fits LDS, N <= 1280), 1 = force the generic fp32 kernel
+extern "C" int flope_yattn_launch(const YAttnP* p, int dtype, int variant, void* stream) {
+  if (p->N < 1) return (int)hipErrorInvalidValue;
+  const int NB = (p->N + 31) / 32;
+  const size_t lds_m = (size_t)64 * (NB * 64 + 16);
+  if (variant == 0 && lds_m <= 160 * 1024) {
+    YDISPATCH(dtype, yattn_mfma_kernel, dim3((p->N + 63) / 64, p->heads), dim3(256), lds_m, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+  }
   const size_t lds = (size_t)16 * p->N * sizeof(float);
-  if (lds > 160 * 1024 || p->N < 1) return (int)hipErrorInvalidValue;      // N <= 2560 tokens (imgsz up to ~1600)
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;                   // N <= 2560 tokens (imgsz up to ~1600)
   YDISPATCH(dtype, yattn_kernel, dim3((p->N + 15) / 16, p->heads), dim3(256), lds, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
 }

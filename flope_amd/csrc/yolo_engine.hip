@@ -26,7 +26,7 @@ extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream);
 extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream);
 extern "C" int flope_yup_launch(const YUpP* p, void* stream);
 extern "C" int flope_yattn_init();
-extern "C" int flope_yattn_launch(const YAttnP* p, int dtype, void* stream);
+extern "C" int flope_yattn_launch(const YAttnP* p, int dtype, int variant, void* stream);
 extern "C" int flope_yletter_launch(const YLetterP* p, int dtype, void* stream);
 extern "C" int flope_ydecode_launch(const YDecodeP* p, void* stream);
 extern "C" int flope_ynms_launch(const YNmsP* p, void* stream);
@@ -69,6 +69,7 @@ struct flope_yolo {
   float* pred = nullptr;
   YLetterP letter; YDecodeP dec; YNmsP nms; YMaskP mask;
   uint8_t* merged = nullptr;
+  int opt_generic_attn = 0;                                   // A/B + parity of the two attention kernels
   double flops = 0.0;
   std::string err;
 };
@@ -358,7 +359,7 @@ int run_ops(flope_yolo* e, void* stream) {
       case Op::DW: s = flope_ydw_launch(&op.dw, e->dtype, stream); break;
       case Op::POOL: s = flope_ypool_launch(&op.pool, e->dtype, stream); break;
       case Op::UP: s = flope_yup_launch(&op.up, stream); break;
-      case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, stream); break;
+      case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, stream); break;
     }
     if (s != 0) return yfail(e, FLOPE_EHIP, op.name + ": " + hipGetErrorString((hipError_t)s));
   }
@@ -607,6 +608,12 @@ extern "C" int flope_yolo_read_tensor(flope_yolo_handle e, const char* name, flo
   const int s = flope_yread_launch(t.ptr, t.is_f32, t.H, t.W, t.C, t.ld, e->dtype, dst_dev, stream);
   if (s) return yfail(e, FLOPE_EHIP, std::string("read_tensor: ") + hipGetErrorString((hipError_t)s));
   return FLOPE_OK;
+}
+
+extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int value) {
+  if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
+  if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
+  return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
 }
 
 extern "C" double flope_yolo_flops(flope_yolo_handle e) { return e ? e->flops : 0.0; }

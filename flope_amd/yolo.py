@@ -146,6 +146,12 @@ class YoloSeg:
             self._check(self.lib.flope_yolo_read_tensor(self.handle, name.encode(), buf.data_ptr(), dims, self._stream()))
         return buf
 
+    def set_option(self, name: str, value: int) -> int:
+        rc = self.lib.flope_yolo_set_option(self.handle, name.encode(), int(value))
+        if rc < 0:
+            self._check(rc)
+        return rc
+
     def flops(self) -> float:
         return float(self.lib.flope_yolo_flops(self.handle))
 

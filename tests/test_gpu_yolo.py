@@ -56,6 +56,21 @@ def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol):
     y.close()
 
 
+def test_attention_kernels_agree(ysd):
+    """C2PSA attention: the MFMA kernel (V^T in LDS, softmax in the accumulator layout) against the generic fp32 kernel
+    on the same qkv map -- the graph output of layer 10 and everything downstream."""
+    from flope_amd.yolo_weights import synthetic_frame
+    img = synthetic_frame(8, 1080, 1920)
+    y = _engine(ysd, 1080, 1920, 1280)
+    y.forward(img)
+    a10, a22 = y.read_tensor("10").cpu(), y.read_tensor("22").cpu()
+    assert y.set_option("generic_attn", 1) == 0
+    y.forward(img)
+    b10, b22 = y.read_tensor("10").cpu(), y.read_tensor("22").cpu()
+    assert _rel(a10, b10) <= 3e-3 and _rel(a22, b22) <= 5e-3, (_rel(a10, b10), _rel(a22, b22))
+    y.close()
+
+
 def _head_rows(y):
     """the device's own float32 head rows as the oracle's `o` dict"""
     o = {}
