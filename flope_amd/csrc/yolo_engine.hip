@@ -41,6 +41,8 @@ namespace {
 thread_local std::string g_yolo_error;
 constexpr double kYoloBnEps = 1e-3;            // ultralytics: BatchNorm2d(eps=0.001)
 constexpr int kRegMax = 16, kNm = 32, kMaxDet = 300;
+constexpr int kSide = 4;                       // side streams: proto, box, class and coefficient branches of the Segment head
+constexpr int kEvents = 3 + kSide;             // features of the three levels ready; one join event per side stream
 
 struct View { int t = -1, off = 0, C = 0; };   // channel slice [off, off + C) of tensor t
 struct Tensor { void* ptr = nullptr; int H = 0, W = 0, C = 0; };
@@ -48,6 +50,8 @@ struct Tensor { void* ptr = nullptr; int H = 0, W = 0, C = 0; };
 struct Op {
   enum Kind { CONV, DW, POOL, UP, ATTN } kind;
   int nt = 4;
+  int stream = 0;                 // 0 = the caller's stream; 1..kSide = internal side streams (independent head branches)
+  int wait_ev = -1, rec_ev = -1;  // event to wait for before / to record after this launch
   YConvP conv; YDwP dw; YPoolP pool; YUpP up; YAttnP attn;
   std::string name;
 };
@@ -70,6 +74,9 @@ struct flope_yolo {
   YLetterP letter; YDecodeP dec; YNmsP nms; YMaskP mask;
   uint8_t* merged = nullptr;
   int opt_generic_attn = 0;                                   // A/B + parity of the two attention kernels
+  int opt_streams = 1;                                        // 1: head branches on side streams (default); 0: one stream
+  hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[kEvents] = {};
   double flops = 0.0;
   std::string err;
 };
@@ -92,6 +99,13 @@ struct Builder {
   flope_yolo* e;
   std::map<std::string, std::pair<const float*, std::vector<int64_t>>> sd;
   int rc = 0;
+  int cur_stream = 0, pending_wait = -1;      // stream of the ops emitted next; event the next op has to wait for
+  void push(Op& op) {
+    op.stream = cur_stream; op.wait_ev = pending_wait; pending_wait = -1;
+    e->ops.push_back(op);
+  }
+  void on_stream(int s, int wait_ev) { cur_stream = s; pending_wait = wait_ev; }
+  void record_after_last(int ev) { if (!e->ops.empty()) e->ops.back().rec_ev = ev; }
 
   bool has(const std::string& k) const { return sd.count(k) != 0; }
   const std::vector<int64_t>* shape(const std::string& k) {
@@ -211,7 +225,7 @@ struct Builder {
     fastdiv_magic((unsigned)c.cg, &c.cg_mg, &c.cg_sh);
     c.out_mode = out_mode; c.dc = out_mode == 2 ? co / 4 : 0;
     e->flops += 2.0 * c.M * (double)rows * cin * k * k;
-    e->ops.push_back(op);
+    push(op);
   }
 
   // nn.Conv2d(cin, cout, 1) with bias -> float32 columns [col0, col0 + cout) of the prediction rows [a0, a0 + H*W)
@@ -268,20 +282,20 @@ struct Builder {
     d.w = (const float*)upload(wf); d.bias = (const float*)upload(bf); d.act = act;
     d.blk = blk; d.blk_stride = blk_stride; d.blk_off = blk_off;
     e->flops += 2.0 * d.H * d.W * (double)c * 9;
-    e->ops.push_back(op);
+    push(op);
   }
 
   void pool(const View& in, const View& out) {
     Op op; op.kind = Op::POOL; op.name = "maxpool5";
     op.pool.in = vptr(in); op.pool.H = vH(in); op.pool.W = vW(in); op.pool.C = in.C; op.pool.ldi = vld(in);
     op.pool.out = vptr(out); op.pool.ldo = vld(out);
-    e->ops.push_back(op);
+    push(op);
   }
   void upsample(const View& in, const View& out) {
     Op op; op.kind = Op::UP; op.name = "upsample2x";
     op.up.in = vptr(in); op.up.H = vH(in); op.up.W = vW(in); op.up.C = in.C; op.up.ldi = vld(in);
     op.up.out = vptr(out); op.up.ldo = vld(out);
-    e->ops.push_back(op);
+    push(op);
   }
 
   // ---- modules (ultralytics nn/modules/block.py) -------------------------------------------------------------------
@@ -340,7 +354,7 @@ struct Builder {
       op.attn.qkv = vptr(full(qkv)); op.attn.N = H * W; op.attn.heads = heads; op.attn.ld = heads * 128;
       op.attn.out = vptr(full(att)); op.attn.ldo = c; op.attn.scale = 1.0f / sqrtf(32.f);
       e->flops += 2.0 * heads * (double)H * W * H * W * (32 + 64);
-      e->ops.push_back(op);
+      push(op);
       const View va = full(att);
       dw(q + ".attn.pe", full(qkv), full(att2), 0, &va, 64, 128, 64);            // (v @ attn^T) + pe(v)
       conv(q + ".attn.proj", full(att2), b, 1, 0, &b);                            // b = b + proj(...)
@@ -352,17 +366,32 @@ struct Builder {
 };
 
 int run_ops(flope_yolo* e, void* stream) {
+  hipStream_t user = (hipStream_t)stream;
+  const bool multi = e->opt_streams != 0;
+  bool used[kSide] = {false, false, false, false};
   for (const Op& op : e->ops) {
+    hipStream_t st = (multi && op.stream > 0) ? e->side[op.stream - 1] : user;
+    if (multi && op.stream > 0) used[op.stream - 1] = true;
+    if (multi && op.wait_ev >= 0 && hipStreamWaitEvent(st, e->ev[op.wait_ev], 0) != hipSuccess) return yfail(e, FLOPE_EHIP, "hipStreamWaitEvent failed");
     int s = 0;
     switch (op.kind) {
-      case Op::CONV: s = flope_yconv_launch(&op.conv, e->dtype, op.nt, stream); break;
-      case Op::DW: s = flope_ydw_launch(&op.dw, e->dtype, stream); break;
-      case Op::POOL: s = flope_ypool_launch(&op.pool, e->dtype, stream); break;
-      case Op::UP: s = flope_yup_launch(&op.up, stream); break;
-      case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, stream); break;
+      case Op::CONV: s = flope_yconv_launch(&op.conv, e->dtype, op.nt, st); break;
+      case Op::DW: s = flope_ydw_launch(&op.dw, e->dtype, st); break;
+      case Op::POOL: s = flope_ypool_launch(&op.pool, e->dtype, st); break;
+      case Op::UP: s = flope_yup_launch(&op.up, st); break;
+      case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, st); break;
     }
-    if (s != 0) return yfail(e, FLOPE_EHIP, op.name + ": " + hipGetErrorString((hipError_t)s));
+    if (s != 0) {
+      for (int i = 0; i < kSide; ++i) if (used[i]) hipStreamSynchronize(e->side[i]);      // leave nothing unordered behind
+      return yfail(e, FLOPE_EHIP, op.name + ": " + hipGetErrorString((hipError_t)s));
+    }
+    if (multi && op.rec_ev >= 0 && hipEventRecord(e->ev[op.rec_ev], st) != hipSuccess) return yfail(e, FLOPE_EHIP, "hipEventRecord failed");
   }
+  for (int i = 0; i < kSide; ++i)           // join: the caller's stream continues only after every branch
+    if (used[i] && (hipEventRecord(e->ev[3 + i], e->side[i]) != hipSuccess || hipStreamWaitEvent(user, e->ev[3 + i], 0) != hipSuccess)) {
+      hipStreamSynchronize(e->side[i]);
+      return yfail(e, FLOPE_EHIP, "joining the head-branch streams failed");
+    }
   return FLOPE_OK;
 }
 
@@ -391,6 +420,10 @@ extern "C" int flope_yolo_create(int device_id, int frame_h, int frame_w, int im
   e->h = e->nh + e->top + (int)nearbyint(dh + 0.1); e->w = e->nw + e->left + (int)nearbyint(dw + 0.1);
   if (e->h % 32 || e->w % 32) { delete e; return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: letterboxed size is not a multiple of 32"); }
   if (hipSetDevice(device_id) != hipSuccess || flope_yattn_init() != 0) { delete e; return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: device setup failed"); }
+  for (int i = 0; i < kSide; ++i)
+    if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) { flope_yolo_destroy(e); return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: hipStreamCreate failed"); }
+  for (int i = 0; i < kEvents; ++i)
+    if (hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) { flope_yolo_destroy(e); return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: hipEventCreate failed"); }
   *out = e;
   return FLOPE_OK;
 }
@@ -401,6 +434,8 @@ extern "C" int flope_yolo_destroy(flope_yolo_handle e) {
   hipDeviceSynchronize();
   for (Tensor& t : e->tensors) if (t.ptr) hipFree(t.ptr);
   for (void* p : e->owned) if (p) hipFree(p);
+  for (int i = 0; i < kSide; ++i) if (e->side[i]) hipStreamDestroy(e->side[i]);
+  for (int i = 0; i < kEvents; ++i) if (e->ev[i]) hipEventDestroy(e->ev[i]);
   delete e;
   return FLOPE_OK;
 }
@@ -469,41 +504,34 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
   b.upsample(o10, b.slice(cat12, 0, c10));
   b.c3k2("model.13", b.full(cat12), o13);
   b.upsample(o13, b.slice(cat15, 0, c13));
-  b.c3k2("model.16", b.full(cat15), b.full(t16));
-  b.conv("model.17", b.full(t16), b.slice(cat18, 0, c17), 2, 1);
-  b.c3k2("model.19", b.full(cat18), b.full(t19));
-  b.conv("model.20", b.full(t19), b.slice(cat21, 0, c20), 2, 1);
-  b.c3k2("model.22", b.full(cat21), b.full(t22));
-  if (b.rc) return b.rc;
-  b.tap("input", b.full(x));
-  const std::pair<const char*, View> named[] = {{"0", b.full(t0)}, {"1", b.full(t1)}, {"2", b.full(t2)}, {"3", b.full(t3)}, {"4", o4},
-      {"5", b.full(t5)}, {"6", o6}, {"7", b.full(t7)}, {"8", b.full(t8)}, {"9", b.full(t9)}, {"10", o10}, {"13", o13},
-      {"16", b.full(t16)}, {"17", b.slice(cat18, 0, c17)}, {"19", b.full(t19)}, {"20", b.slice(cat21, 0, c20)}, {"22", b.full(t22)}};
-  for (const auto& kv : named) b.tap(kv.first, kv.second);
-  // ---- Segment head (nn/modules/head.py): per level box / class / coefficient branches -> float32 prediction rows
-  const View feats[3] = {b.full(t16), b.full(t19), b.full(t22)};
+  // The Segment head's branches only depend on their level's feature map: they go to side streams (proto, box, class,
+  // coefficients) right after that map is produced, and run beside the rest of the neck and beside each other --
+  // 40-odd launches of a few microseconds each that would otherwise queue up behind one another.
+  const char* nm3[3] = {"box", "cls", "coef"};
   int a0 = 0;
-  for (int i = 0; i < 3; ++i) {
-    const View f = feats[i];
+  auto head_level = [&](int i, const View f, int ev_ready) {
     const int H = b.vH(f), W = b.vW(f);
     const std::string si = std::to_string(i);
     const int cb = b.cout(hd + ".cv2." + si + ".0"), cc = b.cout(hd + ".cv3." + si + ".0.1"), cm = b.cout(hd + ".cv4." + si + ".0");
-    if (b.rc) return b.rc;
+    if (b.rc) return;
+    b.on_stream(2, ev_ready);
     const int b1 = b.tensor(H, W, cb), b2 = b.tensor(H, W, cb);
     b.conv(hd + ".cv2." + si + ".0", f, b.full(b1), 1, 1);
     b.conv(hd + ".cv2." + si + ".1", b.full(b1), b.full(b2), 1, 1);
     b.plain(hd + ".cv2." + si + ".2", b.full(b2), a0, 0);
+    b.on_stream(3, ev_ready);
     const int d1 = b.tensor(H, W, f.C), e1 = b.tensor(H, W, cc), d2 = b.tensor(H, W, cc), e2 = b.tensor(H, W, cc);
     b.dw(hd + ".cv3." + si + ".0.0", f, b.full(d1), 1);
     b.conv(hd + ".cv3." + si + ".0.1", b.full(d1), b.full(e1), 1, 1);
     b.dw(hd + ".cv3." + si + ".1.0", b.full(e1), b.full(d2), 1);
     b.conv(hd + ".cv3." + si + ".1.1", b.full(d2), b.full(e2), 1, 1);
     b.plain(hd + ".cv3." + si + ".2", b.full(e2), a0, 4 * kRegMax);
+    b.on_stream(4, ev_ready);
     const int m1 = b.tensor(H, W, cm), m2 = b.tensor(H, W, cm);
     b.conv(hd + ".cv4." + si + ".0", f, b.full(m1), 1, 1);
     b.conv(hd + ".cv4." + si + ".1", b.full(m1), b.full(m2), 1, 1);
     b.plain(hd + ".cv4." + si + ".2", b.full(m2), a0, 4 * kRegMax + e->nc);
-    const char* nm3[3] = {"box", "cls", "coef"};
+    b.on_stream(0, -1);
     const int col[3] = {0, 4 * kRegMax, 4 * kRegMax + e->nc}, cw[3] = {4 * kRegMax, e->nc, kNm};
     for (int k = 0; k < 3; ++k) {
       Tap t; t.is_f32 = 1; t.ptr = e->pred + (size_t)a0 * e->no + col[k]; t.H = H; t.W = W; t.C = cw[k]; t.ld = e->no;
@@ -511,16 +539,34 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
     }
     e->dec.lvl_a0[i] = a0; e->dec.lvl_w[i] = W; e->dec.lvl_stride[i] = 8 << i;
     a0 += H * W;
-  }
-  e->dec.lvl_a0[3] = a0;
+  };
+  b.c3k2("model.16", b.full(cat15), b.full(t16));
+  b.record_after_last(0);
   const int npr = b.cout(hd + ".proto.cv1");
   if (b.rc) return b.rc;
   const int p1 = b.tensor(H8, W8, npr), pu = b.tensor(2 * H8, 2 * W8, npr), p2 = b.tensor(2 * H8, 2 * W8, npr), pr = b.tensor(2 * H8, 2 * W8, kNm);
+  b.on_stream(1, 0);
   b.conv(hd + ".proto.cv1", b.full(t16), b.full(p1), 1, 1);
   b.deconv(hd + ".proto.upsample", b.full(p1), b.full(pu));
   b.conv(hd + ".proto.cv2", b.full(pu), b.full(p2), 1, 1);
   b.conv(hd + ".proto.cv3", b.full(p2), b.full(pr), 1, 1);
+  b.on_stream(0, -1);
+  head_level(0, b.full(t16), 0);
+  b.conv("model.17", b.full(t16), b.slice(cat18, 0, c17), 2, 1);
+  b.c3k2("model.19", b.full(cat18), b.full(t19));
+  b.record_after_last(1);
+  head_level(1, b.full(t19), 1);
+  b.conv("model.20", b.full(t19), b.slice(cat21, 0, c20), 2, 1);
+  b.c3k2("model.22", b.full(cat21), b.full(t22));
+  b.record_after_last(2);
+  head_level(2, b.full(t22), 2);
+  e->dec.lvl_a0[3] = a0;
   if (b.rc) return b.rc;
+  b.tap("input", b.full(x));
+  const std::pair<const char*, View> named[] = {{"0", b.full(t0)}, {"1", b.full(t1)}, {"2", b.full(t2)}, {"3", b.full(t3)}, {"4", o4},
+      {"5", b.full(t5)}, {"6", o6}, {"7", b.full(t7)}, {"8", b.full(t8)}, {"9", b.full(t9)}, {"10", o10}, {"13", o13},
+      {"16", b.full(t16)}, {"17", b.slice(cat18, 0, c17)}, {"19", b.full(t19)}, {"20", b.slice(cat21, 0, c20)}, {"22", b.full(t22)}};
+  for (const auto& kv : named) b.tap(kv.first, kv.second);
   b.tap("proto_up", b.full(pu));
   b.tap("proto", b.full(pr));
   // ---- post-processing buffers ---------------------------------------------------------------------------------------
@@ -613,6 +659,7 @@ extern "C" int flope_yolo_read_tensor(flope_yolo_handle e, const char* name, flo
 extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int value) {
   if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
+  if (!strcmp(name, "streams")) { const int prev = e->opt_streams; e->opt_streams = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
 }
 

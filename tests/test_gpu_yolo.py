@@ -71,6 +71,23 @@ def test_attention_kernels_agree(ysd):
     y.close()
 
 
+def test_head_branch_streams_do_not_change_a_bit(ysd):
+    """The Segment head's branches run on four internal side streams; one stream gives the identical result."""
+    from flope_amd.yolo_weights import synthetic_frame
+    img = synthetic_frame(9, 1080, 1920)
+    y = _engine(ysd, 1080, 1920, 1280)
+    outs = []
+    for streams in (1, 0, 1):
+        y.set_option("streams", streams)
+        boxes, sc, cls, anchor, mask = y.detect(img, 0.1)
+        outs.append((boxes, sc, anchor, mask, y.read_tensor("proto").cpu().numpy(), y.read_tensor("cls2").cpu().numpy()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+    assert len(outs[0][2]) >= 10
+    y.close()
+
+
 def _head_rows(y):
     """the device's own float32 head rows as the oracle's `o` dict"""
     o = {}
@@ -180,8 +197,9 @@ def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path
     assert np.linalg.norm(Rt[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
     # and the detector half against the fp32 oracle: same number of boxes within a pixel, or a marginal candidate differs
     rb, rmask = Y.get_bbox_mask(ysd, img, 1280)
-    if rb.shape == bb.shape:
-        assert np.abs(rb.astype(int) - bb.astype(int)).max() <= 2
+    if rb.shape == bb.shape:                         # near-equal confidences may swap two rows: compare as sets
+        for r in rb.astype(int):
+            assert np.abs(bb.astype(int) - r).max(axis=1).min() <= 2, r
     assert (np.logical_xor(mask > 127, rmask > 127)).mean() < 0.02
 
 
