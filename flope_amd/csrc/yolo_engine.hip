@@ -58,6 +58,10 @@ struct Op {
 
 struct Tap { int is_f32 = 0; const void* ptr = nullptr; int H = 0, W = 0, C = 0, ld = 0; };
 
+struct GraphKey {                 // what a captured detect sequence bakes in
+  const void* frame; void* det; void* count; void* mask; float conf, iou; int max_det, streams, generic_attn;
+};
+
 }  // namespace
 
 struct flope_yolo {
@@ -75,6 +79,9 @@ struct flope_yolo {
   uint8_t* merged = nullptr;
   int opt_generic_attn = 0;                                   // A/B + parity of the two attention kernels
   int opt_streams = 1;                                        // 1: head branches on side streams (default); 0: one stream
+  int opt_graph = 1;                                          // 1: flope_yolo_detect replays a captured hipGraph (default)
+  hipGraphExec_t graph_exec = nullptr;
+  GraphKey graph_key = {};
   hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev[kEvents] = {};
   double flops = 0.0;
@@ -432,6 +439,7 @@ extern "C" int flope_yolo_destroy(flope_yolo_handle e) {
   if (!e) return FLOPE_OK;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
+  if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
   for (Tensor& t : e->tensors) if (t.ptr) hipFree(t.ptr);
   for (void* p : e->owned) if (p) hipFree(p);
   for (int i = 0; i < kSide; ++i) if (e->side[i]) hipStreamDestroy(e->side[i]);
@@ -621,12 +629,8 @@ extern "C" int flope_yolo_forward(flope_yolo_handle e, const uint8_t* frame_dev,
   return run_ops(e, stream);
 }
 
-extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, float conf, float iou, int max_det,
-                                 float* det_dev, int32_t* count_dev, uint8_t* mask_dev, void* stream) {
-  if (!e) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_detect: NULL handle");
-  if (!det_dev || !count_dev || !mask_dev) return yfail(e, FLOPE_EINVAL, "flope_yolo_detect: NULL output");
-  if (max_det < 1 || max_det > kMaxDet) return yfail(e, FLOPE_EINVAL, "flope_yolo_detect: max_det must be within 1..300");
-  if (!(conf >= 0.f && conf < 1.f) || !(iou > 0.f && iou <= 1.f)) return yfail(e, FLOPE_EINVAL, "flope_yolo_detect: bad thresholds");
+static int detect_body(flope_yolo* e, const uint8_t* frame_dev, float conf, float iou, int max_det, float* det_dev,
+                       int32_t* count_dev, uint8_t* mask_dev, void* stream) {
   int rc = flope_yolo_forward(e, frame_dev, stream);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -639,6 +643,40 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   if (!s) s = flope_ymask_launch(&m, e->dtype, stream);
   if (!s) s = flope_resize_linear_u8_launch(e->merged, e->h, e->w, mask_dev, e->H, e->W, stream);
   if (s) return yfail(e, FLOPE_EHIP, std::string("post-processing: ") + hipGetErrorString((hipError_t)s));
+  return FLOPE_OK;
+}
+
+// The detector is ~115 launches of a few microseconds each: issued one by one the host, not the GPU, sets the frame time.
+// With the "graph" option (default) the launch sequence of one (frame buffer, thresholds, output buffers) tuple is captured
+// once into a hipGraph -- head branches as parallel graph branches through the side streams -- and replayed afterwards.
+extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, float conf, float iou, int max_det,
+                                 float* det_dev, int32_t* count_dev, uint8_t* mask_dev, void* stream) {
+  if (!e) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_detect: NULL handle");
+  if (!e->loaded) return yfail(e, FLOPE_ESTATE, "detect before flope_yolo_load_weights");
+  if (!frame_dev || !det_dev || !count_dev || !mask_dev) return yfail(e, FLOPE_EINVAL, "flope_yolo_detect: NULL argument");
+  if (max_det < 1 || max_det > kMaxDet) return yfail(e, FLOPE_EINVAL, "flope_yolo_detect: max_det must be within 1..300");
+  if (!(conf >= 0.f && conf < 1.f) || !(iou > 0.f && iou <= 1.f)) return yfail(e, FLOPE_EINVAL, "flope_yolo_detect: bad thresholds");
+  if (!e->opt_graph) return detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
+  Y_TRY(e, hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_streams, e->opt_generic_attn};
+  if (!e->graph_exec || memcmp(&key, &e->graph_key, sizeof key) != 0) {
+    if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();                              // e.g. the legacy null stream cannot be captured: run eagerly
+      return detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
+    }
+    const int rc = detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
+    const hipError_t ec = hipStreamEndCapture(st, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (ec != hipSuccess || !g) return yfail(e, FLOPE_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+    const hipError_t ei = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ei != hipSuccess) { e->graph_exec = nullptr; return yfail(e, FLOPE_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+    e->graph_key = key;
+  }
+  Y_TRY(e, hipGraphLaunch(e->graph_exec, st));
   return FLOPE_OK;
 }
 
@@ -660,6 +698,7 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
   if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
   if (!strcmp(name, "streams")) { const int prev = e->opt_streams; e->opt_streams = value != 0; return prev; }
+  if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
 }
 

@@ -64,9 +64,14 @@ class YoloSeg:
         ih, iw = C.c_int(), C.c_int()
         self._check(self.lib.flope_yolo_input_size(self.handle, C.byref(ih), C.byref(iw)))
         self.input_hw = (ih.value, iw.value)
+        # persistent device buffers: the captured launch graph bakes their addresses in
         self._det = torch.zeros((MAX_DET, 8), dtype=torch.float32, device=self.device)
         self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._keep = None
+        self._frame_buf = torch.zeros((self.frame_h, self.frame_w, 3), dtype=torch.uint8, device=self.device)
+        self._mask = torch.zeros((self.frame_h, self.frame_w), dtype=torch.uint8, device=self.device)
+        # graph capture needs a real stream: when the caller works on the (uncapturable) default stream the detector runs
+        # on this one, ordered after / before the caller's stream with two events
+        self._own_stream = torch.cuda.Stream(self.device)
 
     def _check(self, rc, handle="self"):
         if rc != 0:
@@ -98,11 +103,14 @@ class YoloSeg:
             self._check(self.lib.flope_yolo_load_weights(self.handle, n, names, ptrs, ndims, shapes))
 
     def _frame(self, frame) -> torch.Tensor:
+        """host or device frame -> the engine's own frame buffer (one H2D / D2D copy, no allocation)"""
         if isinstance(frame, np.ndarray):
             frame = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))
         if frame.dtype != torch.uint8 or tuple(frame.shape) != (self.frame_h, self.frame_w, 3):
             raise ValueError(f"expected a uint8 BGR frame [{self.frame_h},{self.frame_w},3], got {frame.dtype} {tuple(frame.shape)}")
-        return frame.to(self.device).contiguous()
+        if frame.data_ptr() != self._frame_buf.data_ptr():
+            self._frame_buf.copy_(frame, non_blocking=True)
+        return self._frame_buf
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -112,18 +120,22 @@ class YoloSeg:
         f = self._frame(frame)
         with torch.cuda.device(self.device):
             self._check(self.lib.flope_yolo_forward(self.handle, f.data_ptr(), self._stream()))
-        self._keep = f
 
     def detect_device(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET):
-        """-> (det float32 [max_det,8] on the device, count int32 [1] on the device, mask uint8 [H,W] on the device, frame
-        tensor on the device).  Nothing is synchronised."""
+        """-> (det float32 [max_det,8], count int32 [1], mask uint8 [H,W], frame uint8 [H,W,3]): the engine's own device
+        buffers, valid until the next call.  Nothing is synchronised."""
         f = self._frame(frame)
-        mask = torch.empty((self.frame_h, self.frame_w), dtype=torch.uint8, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        st = cur
+        if cur.cuda_stream == 0:
+            st = self._own_stream
+            st.wait_stream(cur)
         with torch.cuda.device(self.device):
             self._check(self.lib.flope_yolo_detect(self.handle, f.data_ptr(), float(conf), float(iou), int(max_det),
-                                                   self._det.data_ptr(), self._count.data_ptr(), mask.data_ptr(), self._stream()))
-        self._keep = f
-        return self._det, self._count, mask, f
+                                                   self._det.data_ptr(), self._count.data_ptr(), self._mask.data_ptr(), st.cuda_stream))
+        if st is not cur:
+            cur.wait_stream(st)
+        return self._det, self._count, self._mask, f
 
     def detect(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET):
         """-> (boxes float32 [n,4] frame xyxy, conf [n], cls [n], anchor [n], mask uint8 [H,W]) as numpy arrays."""

@@ -72,14 +72,17 @@ def test_attention_kernels_agree(ysd):
 
 
 def test_head_branch_streams_do_not_change_a_bit(ysd):
-    """The Segment head's branches run on four internal side streams; one stream gives the identical result."""
+    """The Segment head's branches run on four internal side streams / as parallel branches of the captured hipGraph;
+    one stream, eager launches give the identical result."""
     from flope_amd.yolo_weights import synthetic_frame
     img = synthetic_frame(9, 1080, 1920)
     y = _engine(ysd, 1080, 1920, 1280)
     outs = []
-    for streams in (1, 0, 1):
+    for streams, graph in ((1, 1), (0, 0), (1, 0), (0, 1), (1, 1)):      # captured hipGraph replay and eager launches
         y.set_option("streams", streams)
+        y.set_option("graph", graph)
         boxes, sc, cls, anchor, mask = y.detect(img, 0.1)
+        boxes, sc, cls, anchor, mask = y.detect(img, 0.1)                 # second call: replay of the captured graph
         outs.append((boxes, sc, anchor, mask, y.read_tensor("proto").cpu().numpy(), y.read_tensor("cls2").cpu().numpy()))
     for o in outs[1:]:
         for a, b in zip(outs[0], o):

@@ -17,11 +17,15 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--profile-iters", type=int, default=0, help="run only this many detects (for rocprofv3)")
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1)
     args = ap.parse_args()
     from flope_amd.yolo import YoloSeg
     from flope_amd.yolo_weights import synthetic_frame, synthetic_yolo_state_dict
     y = YoloSeg(1080, 1920, 1280, args.dtype)
     y.load_state_dict(synthetic_yolo_state_dict(0))
+    y.set_option("graph", args.graph)
+    y.set_option("streams", args.streams)
     frame = torch.from_numpy(synthetic_frame(0)).cuda()
     n = args.profile_iters or args.iters
     for _ in range(3 if args.profile_iters else 10):
@@ -34,7 +38,7 @@ def main():
     dt = (time.perf_counter() - t0) / n
     print(json.dumps({"detector_ms_per_frame": round(dt * 1e3, 4), "frames_per_s": round(1 / dt, 1), "detections": int(count.item()),
                       "launches": y.launches(), "gflop_per_frame": round(y.flops() / 1e9, 2),
-                      "tflops": round(y.flops() / dt / 1e12, 2), "input": list(y.input_hw), "dtype": args.dtype}))
+                      "tflops": round(y.flops() / dt / 1e12, 2), "input": list(y.input_hw), "dtype": args.dtype, "graph": args.graph, "streams": args.streams}))
 
 
 if __name__ == "__main__":
