@@ -78,8 +78,11 @@ struct flope_yolo {
   YLetterP letter; YDecodeP dec; YNmsP nms; YMaskP mask;
   uint8_t* merged = nullptr;
   int opt_generic_attn = 0;                                   // A/B + parity of the two attention kernels
-  int opt_streams = 1;                                        // 1: head branches on side streams (default); 0: one stream
-  int opt_graph = 1;                                          // 1: flope_yolo_detect replays a captured hipGraph (default)
+  // Both measured as no gain on MI355X (r02, 1080p / imgsz 1280, yolo11n-seg): the detector is bound by the serial chain of
+  // ~115 short kernels on the GPU, not by host launches (hipGraph replay 1.196 vs eager 1.188 ms), and every cross-stream
+  // dependency costs more than the overlap returns (side streams 1.31 ms eager, 1.45 ms in a graph).  Kept as options.
+  int opt_streams = 0;                                        // 1: head branches on side streams; 0 (default): one stream
+  int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
   hipGraphExec_t graph_exec = nullptr;
   GraphKey graph_key = {};
   hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
@@ -646,9 +649,9 @@ static int detect_body(flope_yolo* e, const uint8_t* frame_dev, float conf, floa
   return FLOPE_OK;
 }
 
-// The detector is ~115 launches of a few microseconds each: issued one by one the host, not the GPU, sets the frame time.
-// With the "graph" option (default) the launch sequence of one (frame buffer, thresholds, output buffers) tuple is captured
-// once into a hipGraph -- head branches as parallel graph branches through the side streams -- and replayed afterwards.
+// "graph" option: the launch sequence of one (frame buffer, thresholds, output buffers) tuple is captured once into a
+// hipGraph (with "streams": head branches as parallel graph branches) and replayed afterwards.  Frees the host; does not
+// shorten the frame on MI355X (see the option defaults above).
 extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, float conf, float iou, int max_det,
                                  float* det_dev, int32_t* count_dev, uint8_t* mask_dev, void* stream) {
   if (!e) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_detect: NULL handle");

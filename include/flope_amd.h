@@ -230,9 +230,10 @@ int flope_yolo_forward(flope_yolo_handle h, const uint8_t* frame_dev, void* stre
  * query only. */
 int flope_yolo_read_tensor(flope_yolo_handle h, const char* name, float* dst_dev, int64_t* dims_out, void* stream);
 /* runtime knobs (A/B variants inside one build; each returns the previous value or <0):
- *   "graph" (default 1): flope_yolo_detect captures its launch sequence into a hipGraph the first time it sees a
+ *   "graph" (default 0): flope_yolo_detect captures its launch sequence into a hipGraph the first time it sees a
  *       (frame_dev, thresholds, output buffers) tuple and replays it afterwards -- keep those pointers stable across frames;
- *   "streams" (default 1): the Segment head's branches run on internal side streams / as parallel graph branches;
+ *   "streams" (default 0): the Segment head's branches run on internal side streams / as parallel graph branches
+ *       (both measured as no gain on MI355X: the detector is a serial chain of short kernels);
  *   "generic_attn" (default 0): C2PSA attention on the generic fp32 kernel instead of the MFMA one. */
 int flope_yolo_set_option(flope_yolo_handle h, const char* name, int value);
 double flope_yolo_flops(flope_yolo_handle h);      /* 2*MAC of one forward (convs + attention) */

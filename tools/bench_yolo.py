@@ -17,8 +17,8 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--profile-iters", type=int, default=0, help="run only this many detects (for rocprofv3)")
-    ap.add_argument("--graph", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0)
     args = ap.parse_args()
     from flope_amd.yolo import YoloSeg
     from flope_amd.yolo_weights import synthetic_frame, synthetic_yolo_state_dict
