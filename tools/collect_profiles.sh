@@ -1,0 +1,37 @@
+#!/bin/bash
+# Evidence run on the GPU box (one gpurun call): rocprofv3 kernel trace + PMC passes of the bench workload, the
+# FETCH_SIZE calibration, and the side benches.  Output under gpurun_out/$1 (default r02).
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
+set -o pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export FLOPE_OPTS=streams=1          # per-launch durations comparable with the in-bench HIP events (profile pass)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/tools/profile_target.py 20 > $OUT/kt.log 2>&1 || exit 11
+echo "kt done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/tools/profile_target.py 4 > $OUT/pmc_sq.log 2>&1 || exit 12
+echo "pmc_sq done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/profile_target.py 4 > $OUT/pmc_fetch.log 2>&1 || exit 13
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/profile_target.py 4 > $OUT/pmc_write.log 2>&1 || exit 14
+echo "pmc fetch/write done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- $ROOT/build/fetch_calib > $OUT/calib.log 2>&1 || exit 15
+echo "calib done"
+unset FLOPE_OPTS
+cd $ROOT
+python tools/summarize_prof.py $OUT/kt $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write > $OUT/summary.txt
+python tools/summarize_prof.py $OUT/calib > $OUT/calib_summary.txt
+python tools/roofline_table.py $OUT > $OUT/roofline.md
+python tools/make_traffic_json.py $OUT > $OUT/traffic.json
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 16
+echo "bench done"
+python tools/bench_e2e.py yolo 4 16 31 > $OUT/e2e.txt 2>&1
+python tools/bench_yolo.py > $OUT/yolo_bench.json 2> $OUT/yolo_bench.err
+python tools/latency.py > $OUT/latency.txt 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_yolo -- python3 $ROOT/tools/bench_yolo.py --profile-iters 20 > $OUT/kt_yolo.log 2>&1
+cd $ROOT
+python tools/summarize_prof.py $OUT/kt_yolo > $OUT/yolo_summary.txt
+tail -3 $OUT/bench.json | cut -c1-600
+cat $OUT/calib_summary.txt
