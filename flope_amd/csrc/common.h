@@ -118,6 +118,9 @@ struct ConvP {
   // conv_split_finalize adds them up with bias / residual / ReLU.  ksplit <= 1: off.
   int ksplit;
   float* split_ws;
+  // conv_stag row bands on maps wider than 64 columns: tiles are 8 rows x one of nseg 64-column segments
+  // (tiles_per_image = Ho / 8 * nseg); 0 / 1 = full-width bands
+  int nseg;
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

@@ -92,13 +92,25 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   //   xoff[t][pt] LDS byte offset of this lane's pixel fragment for tap t (buffer / ring slot are immediates)
   // round rr moves pieces rr*512 + wave*64 + lane: pixel rr*128 + wave*16 + (lane>>2), whose swizzle term
   // ((pixel >> 2) & 3) does not depend on rr or wave -> one per-lane offset + a uniform rr stride
-  unsigned psrc0;
-  {
-    const int q = wave * 64 + lane;
+  // ROWS on maps wider than 64 columns (p.nseg > 1: layer 1 of 512 x 512 crops is 128 wide): a tile is 8 rows x one
+  // 64-column SEGMENT; its patch is 10 rows x 66 columns, stored in LDS at a pitch of kSegPitch pixels, and patch pixel
+  // (pr, pc) comes from input pixel (R0 + pr, 64 s0 + pc) -- the per-lane source offsets below carry that mapping, the
+  // LDS side does not change.
+  constexpr int kSegPitch = 66;
+  const bool seg = ROWS && p.nseg > 1;
+  const int pitch = seg ? kSegPitch : p.Wip;
+  unsigned psrc[PT];
+#pragma unroll
+  for (int rr = 0; rr < PT; ++rr) {
+    const int q = rr * 512 + wave * 64 + lane;
     const int pi = q >> 2, js = (q & 3) ^ ((pi >> 2) & 3);
-    psrc0 = (unsigned)(pi * (int)pixB + js * 16);
+    int spix = pi;                                         // source pixel, relative to the patch origin
+    if (seg) {
+      const int pc_ = min(pi, 10 * kSegPitch - 1), pr_ = pc_ / kSegPitch;
+      spix = pr_ * p.Wip + (pc_ - pr_ * kSegPitch);
+    }
+    psrc[rr] = (unsigned)(spix * (int)pixB + js * 16);
   }
-  const size_t round_stride = 128 * pixB;
   const int nbody = nhc / 2 / KSP, body0 = ks * nbody;      // bodies (= pairs of half-chunks = 64 input channels) of this workgroup
   const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + (size_t)body0 * 9 * (2 * TILE_B) + wave * 1024;   // + g*8192 for op g of a double tile
   const unsigned lane16 = lane * 16;
@@ -110,15 +122,18 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
 
   // ---- tile geometry: wave-uniform part (first pixel, patch origin) and per-lane part (xoff, output offsets)
-  int m0, mend, R0;                                        // current tile
+  int m0, mend, R0, mc0 = 0;                               // current tile (mc0: first output column, ROWS segments)
   const char* patch_src;
-  int n_m0 = 0, n_mend = 0, n_R0 = 0;                      // next tile of this workgroup
+  int n_m0 = 0, n_mend = 0, n_R0 = 0, n_mc0 = 0;           // next tile of this workgroup
   const char* n_patch_src = nullptr;
   bool has_next;
-#define TILE_GEOM(tile_, m0_, mend_, R0_, src_)                                                                \
+#define TILE_GEOM(tile_, m0_, mend_, R0_, mc_, src_)                                                           \
   do {                                                                                                         \
+    mc_ = 0;                                                                                                   \
     if constexpr (ROWS) {                                                                                      \
-      const int b0_ = (tile_) / p.tiles_per_image, j0_ = (tile_) - b0_ * p.tiles_per_image;                    \
+      const int b0_ = (tile_) / p.tiles_per_image, jj_ = (tile_) - b0_ * p.tiles_per_image;                    \
+      const int ns_ = max(p.nseg, 1), j0_ = jj_ / ns_;                                                         \
+      mc_ = (jj_ - j0_ * ns_) * 64;                                                                            \
       m0_ = b0_ * p.Hop + j0_ * 8;                                                                             \
       mend_ = m0_ + BM;                                                                                        \
       R0_ = b0_ * p.Hip + j0_ * 8;                                                                             \
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       const int b0_ = fastdiv(m0_, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0_ - b0_ * HoWo, p.mg_w, p.sh_w);        \
       R0_ = b0_ * p.Hip + ho0_;                                                                                \
     }                                                                                                          \
-    src_ = (const char*)p.in + (size_t)R0_ * rowB;                                                             \
+    src_ = (const char*)p.in + (size_t)R0_ * rowB + (size_t)(mc_) * pixB;                                      \
   } while (0)
   // ROWS: the four pixel tiles of a wave are 16 pixels apart in one row -> same swizzle term, offsets differ by
   // 16 * 64 B, which folds into the ds_read immediate: 9 address registers instead of 36
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     _Pragma("unroll") for (int pt = 0; pt < (ROWS ? 1 : MT); ++pt) {                                           \
       int pi0_;                                                                                                \
       if constexpr (ROWS) {                                                                                    \
-        pi0_ = (group * 4 + wpx) * p.Wip + pcol;                                                               \
+        pi0_ = (group * 4 + wpx) * pitch + pcol;                                                               \
       } else {                                                                                                 \
         const int mm_ = m0 + group * GP + wpx * 64 + pt * 16 + pcol;                                           \
         const int m_ = min(mm_, mend - 1);                                                                     \
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         pi0_ = (b_ * p.Hip + ho_ - R0) * p.Wip + wo_;                                                          \
       }                                                                                                        \
       _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                          \
-        const int pi = pi0_ + (t / 3) * p.Wip + (t % 3);                                                       \
+        const int pi = pi0_ + (t / 3) * pitch + (t % 3);                                                       \
         xoff[t][pt] = (pi << 6) + ((g ^ ((pi >> 2) & 3)) << 4);                                                \
       }                                                                                                        \
     }                                                                                                          \
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #define ISSUE_PATCH(src_, buf_)                                                                                \
   do {                                                                                                         \
     _Pragma("unroll") for (int rr = 0; rr < PT; ++rr)                                                          \
-      GLDS16((src_) + rr * round_stride + psrc0, Ps + (buf_) * PATCH_B + (rr * 512 + wave * 64) * 16);         \
+      GLDS16((src_) + psrc[rr], Ps + (buf_) * PATCH_B + (rr * 512 + wave * 64) * 16);                          \
   } while (0)
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define BARRIER()                                                                                              \
@@ -210,14 +225,14 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   } while (0)
 
   // byte offset of this lane's 16 channels of pixel tile pt in the padded NHWC output (clamped to a legal pixel)
-  auto rows_off = [&](int rowbase, int pt) -> size_t {      // ROWS: rowbase = the tile's first padded output row
-    const int col = min(pt * 16 + pcol, p.Wo - 1);
+  auto rows_off = [&](int rowbase, int colbase, int pt) -> size_t {   // ROWS: the tile's first padded output row / column
+    const int col = min(colbase + pt * 16 + pcol, p.Wo - 1);
     return ((((size_t)(rowbase + group * 4 + wpx + 1)) * p.Wop + col + 1) * p.Cout + cb) * 2;
   };
   auto out_off = [&](int pt, bool& valid) -> size_t {
     if constexpr (ROWS) {
-      valid = pt * 16 + pcol < p.Wo;
-      return rows_off(m0, pt);
+      valid = mc0 + pt * 16 + pcol < p.Wo;
+      return rows_off(m0, mc0, pt);
     } else {
       const int mm = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
       valid = mm < mend;
@@ -230,9 +245,9 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 
   // ---- first tile of this workgroup + the one after it
   int tile = lb;
-  TILE_GEOM(tile, m0, mend, R0, patch_src);
+  TILE_GEOM(tile, m0, mend, R0, mc0, patch_src);
   has_next = tile + G < p.total_tiles;
-  if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
+  if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_mc0, n_patch_src);
   LANE_SETUP();
 
   // ---- residual of the FIRST tile: loaded before anything else (oldest VM ops, so the wait below covers them) and
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     }                                                                                                          \
     if constexpr (RES && ROWS && (D) == 6) {   /* residual of the NEXT tile (of this one again at the very end) */ \
       _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                      \
-        const char* rp_ = (const char*)p.res + rows_off(has_next ? n_m0 : m0, pt);                             \
+        const char* rp_ = (const char*)p.res + rows_off(has_next ? n_m0 : m0, has_next ? n_mc0 : mc0, pt);     \
         rq[pt][0] = *(const u32x4*)rp_;                                                                        \
         rq[pt][1] = *(const u32x4*)(rp_ + 16);                                                                 \
       }                                                                                                        \
@@ -473,9 +488,9 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     if (!has_next) break;
     // ---- next tile: geometry, address table; the step stream (ring, patch buffers) just continues
     tile += G;
-    m0 = n_m0; mend = n_mend; R0 = n_R0; patch_src = n_patch_src;
+    m0 = n_m0; mend = n_mend; R0 = n_R0; mc0 = n_mc0; patch_src = n_patch_src;
     has_next = tile + G < p.total_tiles;
-    if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_patch_src);
+    if (has_next) TILE_GEOM(tile + G, n_m0, n_mend, n_R0, n_mc0, n_patch_src);
     if constexpr (!ROWS) LANE_SETUP();          // ROWS: every tile has the first tile's address table
     dn -= ND;
     hc = 2 * body0;
@@ -764,7 +779,8 @@ extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks
     if (p->Cout < 128 || p->res || pt < 4 || pt == 7 || grid_blocks != p->total_tiles * (p->ksplit > 1 ? p->ksplit : 1) || p->ds_Cin % 64 || !p->ds_w) return (int)hipErrorInvalidValue;
     if (dtype == 0) stag_dsf_launch<bf16_t>(*p, pt, grid_blocks, lds, st); else stag_dsf_launch<f16_t>(*p, pt, grid_blocks, lds, st);
   } else if (p->per_image == 2) {          // ROWS geometry: 8-row bands of one image (p->tiles_per_image bands per image)
-    if (p->Cout != 64 || p->Wo > 64 || p->Ho % 8 || (pt != 3 && pt != 5 && pt != 6 && pt != 8) || ((pt & 1) && p->Cin != 64)) return (int)hipErrorInvalidValue;
+    if (p->Cout != 64 || (p->Wo > 64 && p->nseg != (p->Wo + 63) / 64) || p->Ho % 8 || (pt != 3 && pt != 5 && pt != 6 && pt != 8) || ((pt & 1) && p->Cin != 64)) return (int)hipErrorInvalidValue;
+    if (p->nseg > 1 && (pt < 6 || p->tiles_per_image != (p->Ho / 8) * p->nseg)) return (int)hipErrorInvalidValue;   // 10 x 66 pixels x 4 pieces = 2640 <= 6 x 512
     if (dtype == 0) { if (p->res) stag_rows_launch<bf16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<bf16_t, false>(*p, pt, grid_blocks, lds, st); }
     else            { if (p->res) stag_rows_launch<f16_t, true>(*p, pt, grid_blocks, lds, st); else stag_rows_launch<f16_t, false>(*p, pt, grid_blocks, lds, st); }
   } else if (p->Cout == 64) { if (dtype == 0) GO(bf16_t, 64); else GO(f16_t, 64); }

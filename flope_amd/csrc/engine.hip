@@ -61,7 +61,7 @@ struct Conv {
   // device weights
   void* w_packed = nullptr;    // MFMA image (16-bit)
   void* w_stag = nullptr;      // conv_stag image (16-bit), 3x3 s1 Cout >= 128 only
-  int stag = 0, stag_patch_bytes = 0; size_t stag_lds = 0;
+  int stag = 0, stag_patch_bytes = 0, nseg = 1; size_t stag_lds = 0;
   float* w_naive = nullptr;    // [ky][kx][ci][cout]
   float* bias = nullptr;
   // folded shortcut (conv_stag DSF): on a 1x1 downsample conv, folded = 1 means "computed inside layerX.0.conv2";
@@ -90,7 +90,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_gstag = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_gstag = 1, opt_rowseg = 1;
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -214,12 +214,18 @@ void plan_conv(flope_engine* e, Conv& c) {
     const size_t lds = (size_t)6 * sbn * 64 + (size_t)2 * P * 8192;   // 3 double tiles + 2 patch buffers
     if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }
     // layer-1 shape: 8-row bands of one image per tile (constant tile geometry, 7 bands per 56-row image)
+    c.nseg = 1;
     if (c.cout == 64 && e->opt_stag >= 3 && c.hout % 8 == 0 && c.wout <= 64) {
       int Pr = (int)(((long)10 * Wip * 4 + 511) / 512);
       // odd Pr (3, 5) = the instantiations that keep the 72 KB weight panel of a 64 -> 64 layer resident in LDS
       if (c.cin == 64 && Pr <= 5) Pr = Pr <= 3 ? 3 : 5; else Pr = Pr <= 6 ? 6 : 8;
       const size_t ldsr = ((Pr & 1) ? (size_t)18 * 4096 : (size_t)6 * sbn * 64) + (size_t)2 * Pr * 8192;
       if (Pr <= 8 && ldsr <= kLdsMax) { c.stag = 2; c.stag_patch_bytes = Pr; c.stag_lds = ldsr; }
+    } else if (c.cout == 64 && e->opt_stag >= 3 && e->opt_rowseg && c.hout % 8 == 0 && c.wout > 64) {
+      // wide maps (512 x 512 crops: layer 1 is 128 x 128): 8-row bands cut into 64-column segments, 10 x 66-pixel patches
+      // (2640 pieces -> 6 DMA rounds), ring weights
+      c.stag = 2; c.stag_patch_bytes = 6; c.nseg = (c.wout + 63) / 64;
+      c.stag_lds = (size_t)6 * sbn * 64 + (size_t)2 * 6 * 8192;
     }
   }
   // 3x3 stride-2 convs: the gathered-tile variant of the same 8-wave structure (conv_gstag)
@@ -465,6 +471,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value != 0; return prev; }
+  else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
@@ -613,7 +620,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         p.res = nullptr; p.bias = c.bias_fused;
         p.ds_in = vb[cd.in_buf].ptr; p.ds_w = cd.w_ds_stag; p.ds_Hip = cd.hin + 2; p.ds_Wip = cd.win + 2; p.ds_Cin = cd.cin;
       }
-      if (c.stag == 2) { p.per_image = 2; p.tiles_per_image = c.hout / 8; p.mtiles = batch * p.tiles_per_image; p.total_tiles = p.mtiles; }
+      if (c.stag == 2) { p.per_image = 2; p.nseg = c.nseg; p.tiles_per_image = c.hout / 8 * c.nseg; p.mtiles = batch * p.tiles_per_image; p.total_tiles = p.mtiles; }
       // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile); the
       // row-band kernel is always persistent and shares the CUs with the other batch slices in flight
       int gridb = (e->opt_persist && c.ds_conv < 0)
@@ -845,6 +852,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
     if (c.stag == 3) { snprintf(line, sizeof line, "%s: 3x3 s2 %d->%d out %dx%d conv_gstag 256x128 (gathered tiles) lds=147456\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
+    if (c.stag == 2 && c.nseg > 1) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x %d column segments of 64 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.nseg, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);

@@ -156,33 +156,19 @@ __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ feat
   f32x4 acc[2][2];                                          // [image tile][K parity]: 4 independent chains
 #pragma unroll
   for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-  // Software pipeline, PD blocks of 32 k deep: with one block in flight the kernel was a chain of 16 L2 round trips
-  // (19 us for 4 us of MFMA issue); loads run PD blocks ahead and are unconditional (blocks past the end re-read the
-  // last one) so the compiler's counted vmcnt never collapses into a full drain.
-  constexpr int PD = 4;
-  f32x4 a0[PD], a1[PD], f0[PD][2], f1[PD][2];
-  const int klast = K - 32;
-  auto load_blk = [&](int k0, int s_) {
-    a0[s_] = *(const f32x4*)(wrow + k0); a1[s_] = *(const f32x4*)(wrow + k0 + 16);
+#pragma unroll 2
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const f32x4 a0 = *(const f32x4*)(wrow + k0), a1 = *(const f32x4*)(wrow + k0 + 16);
+    f32x4 f0[2], f1[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { f0[s_][t] = *(const f32x4*)(frow[t] + k0); f1[s_][t] = *(const f32x4*)(frow[t] + k0 + 16); }
-  };
+    for (int t = 0; t < 2; ++t) { f0[t] = *(const f32x4*)(frow[t] + k0); f1[t] = *(const f32x4*)(frow[t] + k0 + 16); }
 #pragma unroll
-  for (int s_ = 0; s_ < PD; ++s_) load_blk(min(s_ * 32, klast), s_);
-  for (int k0 = 0; k0 < K; k0 += 32 * PD) {
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int s_ = 0; s_ < PD; ++s_) {
-      if (k0 + s_ * 32 < K) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s_][s], f0[s_][t][s], acc[t][0], 0, 0, 0);
-            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s_][s], f1[s_][t][s], acc[t][1], 0, 0, 0);
-          }
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], f0[t][s], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], f1[t][s], acc[t][1], 0, 0, 0);
       }
-      load_blk(min(k0 + (s_ + PD) * 32, klast), s_);
-    }
   }
   // D: col = lane&15 = image, row = 4*(lane>>4)+reg = output n
   const f32x4 bias = *(const f32x4*)(b1 + n0 + 4 * g);
@@ -239,24 +225,14 @@ __global__ __launch_bounds__(256) void fc2_procrustes_kernel(const float* __rest
   for (int j = 0; j < 9; ++j) acc[j] = 0.f;
   const float* h = hidden + (size_t)img * K;
   if ((K & 3) == 0) {
-    // all loads of PD chunks in flight before the first multiply (one chunk = this lane's 4 k of every row of W2)
-    constexpr int PD = 4;
-    for (int kb = lane * 4; kb < K; kb += 256 * PD) {
-      f32x4 hv[PD], wv[PD][9];
+#pragma unroll 2
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 hv = *(const f32x4*)(h + k);
+      f32x4 wv[9];
 #pragma unroll
-      for (int s_ = 0; s_ < PD; ++s_) {
-        const int k = min(kb + s_ * 256, K - 4);
-        hv[s_] = *(const f32x4*)(h + k);
+      for (int j = 0; j < 9; ++j) wv[j] = *(const f32x4*)(W2 + (size_t)j * K + k);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) wv[s_][j] = *(const f32x4*)(W2 + (size_t)j * K + k);
-      }
-#pragma unroll
-      for (int s_ = 0; s_ < PD; ++s_)
-        if (kb + s_ * 256 < K) {
-#pragma unroll
-          for (int j = 0; j < 9; ++j)
-            acc[j] += hv[s_][0] * wv[s_][j][0] + hv[s_][1] * wv[s_][j][1] + hv[s_][2] * wv[s_][j][2] + hv[s_][3] * wv[s_][j][3];
-        }
+      for (int j = 0; j < 9; ++j) acc[j] += hv[0] * wv[j][0] + hv[1] * wv[j][1] + hv[2] * wv[j][2] + hv[3] * wv[j][3];
     }
   } else {
     for (int k = lane; k < K; k += 64)

@@ -134,6 +134,31 @@ def test_reference_true_shape_512(state_dict):
     e.close()
 
 
+@pytest.mark.parametrize("H,W,B", [(512, 512, 5), (320, 640, 3), (288, 400, 2)])
+def test_layer1_column_segment_bands_vs_emulating_oracle(state_dict, H, W, B):
+    """Layer 1 of crops wider than 256 pixels (the reference's own 512 x 512: a 128-wide map) runs as 8-row bands cut
+    into 64-column segments (10 x 66-pixel patches, per-lane DMA source mapping).  512x512: two full segments, 16 bands,
+    B = 5 -> 160 tiles, some workgroups walk two tiles; 320x640: 160 wide = 2.5 segments (ragged last segment);
+    288x400: 72 x 100 map (Ho % 8 == 0, 1.56 segments).  Same result as the flat-tile kernel (rowseg=0) up to fp32
+    summation order, and both within the 16-bit tolerance of the emulating oracle."""
+    torch.manual_seed(15)
+    x = torch.rand(B, 3, H, W)
+    emu = O.forward_stages_emulated(state_dict, x, torch.float16)
+    e = _engine(state_dict, H, W, B, "f16")
+    assert "column segments" in e.describe_plan()
+    r9, _ = _run(e, x)
+    got = {s: e.read_stage(s, B).cpu() for s in ("pool", "layer1.0", "layer1.1", "layer2.0", "layer4.1")}
+    for s, g in got.items():
+        assert _rel(g, emu[s]) <= 2e-3, (s, _rel(g, emu[s]))
+    assert _rel(r9, emu["r9"]) <= 2e-3
+    e2 = _engine(state_dict, H, W, B, "f16", rowseg=0)
+    assert "column segments" not in e2.describe_plan()
+    r9b, _ = _run(e2, x)
+    assert _rel(e2.read_stage("layer1.1", B).cpu(), got["layer1.1"]) <= 3e-4
+    assert (r9 - r9b).abs().max() <= 2e-3
+    e.close(); e2.close()
+
+
 def test_full_batch_properties_cfg2(state_dict):
     """B = 256 at 224x224 (the bench workload): size-independent properties."""
     B = 256
