@@ -230,22 +230,229 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form (r02, default).  The r02 ablations of the kernel above (B = 256, 141 us on that box): without the MFMA
+// phase 92 us, without MFMA + input loads + stores still 82 us -- the skeleton, not the arithmetic, was the cost, and its
+// largest item was the 28 KB weight image that each of the 12,544 workgroups streams L2 -> LDS for itself (351 MB per
+// launch at the chip's ~7 TB/s DMA rate).  Here a grid of two workgroups per CU walks the tiles: the weights are staged
+// once per workgroup, the conv-output buffer no longer aliases them (LDS = 28 + 13 + 37 KB), the input window of the
+// NEXT tile is loaded into registers before the MFMA phase and written to LDS after it (its latency hides behind the
+// MFMAs, and LDS is written while the other phase's buffer is idle), and a tile costs two barriers instead of four.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoolP p) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int W_BYTES = 7 * 64 * 64;
+  constexpr int PR = 39, PC = 42;
+  constexpr int P_BYTES = ((PR * PC * 8 + 15) / 16) * 16;
+  constexpr int CR = 17, NQ = CR * CR;
+  constexpr int MT = 5, NT = 4, NI = 7;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ws = smem;
+  char* const Ps = smem + W_BYTES;
+  char* const Cs = smem + W_BYTES + P_BYTES;       // [NQ][64 ch] conv outputs (own region: Ws stays resident)
+  (void)NQ;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int G = gridDim.x, total = p.B * p.tiles_y * p.tiles_x;
+  const int lb = xcd_remap(blockIdx.x, G);
+
+  for (int i = wave; i < W_BYTES / 1024; i += 4) GLDS16((const char*)p.w + i * 1024 + lane * 16, Ws + i * 1024);
+
+  // ---- staging geometry of this thread (tile independent): window column c, rows r0 + 6k
+  const bool stager = tid < 6 * PC;
+  const int r0 = tid / PC, c = tid - r0 * PC;
+  const int estep = p.in_format == 0 ? 1 : 3;
+  const size_t img_elems = (size_t)3 * p.H * p.W;
+  const int plane = p.H * p.W;
+  unsigned raw[NI][3];                              // the next tile's window as loaded (bit patterns), converted after the MFMAs
+  unsigned okmask = 0;
+  auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {
+    tx = tile % p.tiles_x; const int q = tile / p.tiles_x;
+    ty = q % p.tiles_y; img = q / p.tiles_y;
+  };
+  auto issue_loads = [&](int tile) {
+    if (!stager) return;
+    int tx, ty, img;
+    tile_origin(tile, tx, ty, img);
+    const int py0 = 2 * (2 * (ty * 8) - 1) - 3, px0 = 2 * (2 * (tx * 8) - 1) - 3;
+    const int x = px0 + c;
+    const bool okx = x >= 0 && x < p.W;
+    const int xoffs = min(max(x, 0), p.W - 1) * estep;
+    okmask = 0;
+    int off[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int r = r0 + 6 * k, y = py0 + r;
+      if (okx && r < PR && y >= 0 && y < p.H) okmask |= 1u << k;
+      off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;
+    }
+    if (p.in_format == 0) {
+      const float* s = (const float*)p.x + (size_t)img * img_elems;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        raw[k][0] = __builtin_bit_cast(unsigned, s[off[k]]); raw[k][1] = __builtin_bit_cast(unsigned, s[off[k] + plane]);
+        raw[k][2] = __builtin_bit_cast(unsigned, s[off[k] + 2 * plane]);
+      }
+    } else if (p.in_format == 3) {
+      const unsigned char* s = (const unsigned char*)p.x + (size_t)img * img_elems;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) { raw[k][0] = s[off[k]]; raw[k][1] = s[off[k] + 1]; raw[k][2] = s[off[k] + 2]; }
+    } else {
+      const unsigned short* s = (const unsigned short*)p.x + (size_t)img * img_elems;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) { raw[k][0] = s[off[k]]; raw[k][1] = s[off[k] + 1]; raw[k][2] = s[off[k] + 2]; }
+    }
+  };
+  auto write_window = [&]() {
+    if (!stager) return;
+    const bool same = (p.in_format == 1) == (sizeof(T) == 2 && std::is_same<T, bf16_t>::value);
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      u32x2 px;
+      if (p.in_format == 0)
+        px = pack4<T>(__builtin_bit_cast(float, raw[k][0]), __builtin_bit_cast(float, raw[k][1]), __builtin_bit_cast(float, raw[k][2]));
+      else if (p.in_format == 3)
+        px = pack4<T>((float)raw[k][0] / 255.0f, (float)raw[k][1] / 255.0f, (float)raw[k][2] / 255.0f);
+      else if (same)
+        px = u32x2{raw[k][0] | (raw[k][1] << 16), raw[k][2]};
+      else if (p.in_format == 1)
+        px = pack4<T>(to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][0])), to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][1])),
+                      to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][2])));
+      else
+        px = pack4<T>(to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][0])), to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][1])),
+                      to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][2])));
+      if (r0 + 6 * k < PR) *(u32x2*)(Ps + (tid + 6 * PC * k) * 8) = ((okmask >> k) & 1u) ? px : u32x2{0u, 0u};
+    }
+  };
+
+  // ---- MFMA geometry of this lane (tile independent)
+  int xo[MT], qidx[MT];
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    const int t = wave * MT + pt;
+    int qr, qc;
+    if (t < CR) { qr = t; qc = r16; }
+    else if (t == CR) { qr = r16; qc = CR - 1; }
+    else { qr = CR - 1; qc = CR - 1; }
+    qidx[pt] = (t < CR + 1 || (t == CR + 1 && r16 == 0)) ? qr * CR + qc : -1;
+    xo[pt] = (2 * qr * PC + 2 * qc) * 8 + g * 16;
+  }
+  const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
+  const int wo_ = r16 * 64 + ((g ^ wsw) << 4);
+  f32x4 b4[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) b4[ct] = *(const f32x4*)(p.bias + g * 16 + ct * 4);
+
+  int tile = lb;
+  if (tile < total) { issue_loads(tile); write_window(); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (; tile < total; tile += G) {
+    int tx, ty, img;
+    tile_origin(tile, tx, ty, img);
+    const int cr0 = 2 * (ty * 8) - 1, cc0 = 2 * (tx * 8) - 1;
+    const bool has_next = tile + G < total;
+    if (has_next) issue_loads(tile + G);           // in flight during the MFMA phase
+    asm volatile("" ::: "memory");
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      frag wf[NT], xf[MT];
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(Ws + ky * 4096 + ct * 1024 + wo_);
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) xf[pt] = *(const frag*)(Ps + xo[pt] + ky * (PC * 8));
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], acc[pt][ct]);
+    }
+    __syncthreads();                               // Ps is free (and the previous tile's pool has finished with Cs)
+    if (has_next) write_window();
+    {
+      const bool edge = cr0 < 0 || cc0 < 0 || cr0 + CR > p.Hs || cc0 + CR > p.Ws;
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) {
+        const int q = qidx[pt];
+        if (q >= 0) {
+          u32x4 o[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+              const int ch = h * 8 + w2 * 2;
+              o[h][w2] = pk_out16<T>(pack2<T>(acc[pt][ch >> 2][ch & 3], acc[pt][(ch + 1) >> 2][(ch + 1) & 3]), true);
+            }
+          if (edge) {
+            const int qr = q / CR, qc = q - qr * CR;
+            const int cr = cr0 + qr, cc = cc0 + qc;
+            if (!(cr >= 0 && cr < p.Hs && cc >= 0 && cc < p.Ws)) { o[0] = u32x4{0u, 0u, 0u, 0u}; o[1] = o[0]; }
+          }
+          *(u32x4*)(Cs + q * 128 + (((2 * g) ^ (q & 7)) << 4)) = o[0];
+          *(u32x4*)(Cs + q * 128 + (((2 * g + 1) ^ (q & 7)) << 4)) = o[1];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 8; i += 256) {
+      const int cg = i & 7, pp = i >> 3;
+      const int pr = pp >> 3, pc = pp & 7;
+      const int oy = ty * 8 + pr, ox = tx * 8 + pc;
+      if (oy >= p.Hq || ox >= p.Wq) continue;
+      u32x4 o = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int q = (2 * pr + dy) * CR + 2 * pc + dx;
+          const u32x4 v = *(const u32x4*)(Cs + q * 128 + ((cg ^ (q & 7)) << 4));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
+        }
+      char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
+      *(u32x4*)dst = o;
+    }
+  }
+}
+
 extern "C" size_t flope_stem_pool_lds() { return 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16; }
 
 extern "C" int flope_stem_pool_init() {
   hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)stem_pool_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   return (int)e;
 }
 
+// persist_blocks > 0: the persistent kernel on that many workgroups (two per CU); 0: one workgroup per tile
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq,
-                                      int Wq, const void* w, const float* bias, void* out, int dtype, void* stream) {
+                                      int Wq, const void* w, const float* bias, void* out, int dtype, int persist_blocks,
+                                      void* stream) {
   StemPoolP p;
   p.x = x; p.out = out; p.w = w; p.bias = bias; p.in_format = in_format;
   p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws_; p.Hq = Hq; p.Wq = Wq;
   p.tiles_y = (Hq + 7) / 8; p.tiles_x = (Wq + 7) / 8;
-  const dim3 grid(B * p.tiles_y * p.tiles_x), block(256);
+  const dim3 block(256);
+  if (persist_blocks > 0) {
+    const int total = B * p.tiles_y * p.tiles_x;
+    const dim3 pgrid(persist_blocks < total ? persist_blocks : total);
+    const size_t plds = 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16 + 17 * 17 * 128;
+    if (dtype == 0) hipLaunchKernelGGL(stem_pool_persist_kernel<bf16_t>, pgrid, block, plds, (hipStream_t)stream, p);
+    else            hipLaunchKernelGGL(stem_pool_persist_kernel<f16_t>, pgrid, block, plds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+  }
+  const dim3 grid(B * p.tiles_y * p.tiles_x);
   const size_t lds = flope_stem_pool_lds();
   if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, grid, block, lds, (hipStream_t)stream, p);
   else            hipLaunchKernelGGL(stem_pool_kernel<f16_t>, grid, block, lds, (hipStream_t)stream, p);
