@@ -238,7 +238,10 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
 // once per workgroup, the conv-output buffer no longer aliases them (LDS = 28 + 13 + 37 KB), the input window of the
 // NEXT tile is loaded into registers before the MFMA phase and written to LDS after it (its latency hides behind the
 // MFMAs, and LDS is written while the other phase's buffer is idle), and a tile costs two barriers instead of four.
-template <typename T>
+// FMT = the crop batch's FLOPE_IN_* format as a template argument: with a runtime branch around the window loads the
+// compiler has to merge the branches' destination registers right behind them, i.e. waits for the loads BEFORE the MFMA
+// phase -- the prefetch became a stall (measured: 166 us instead of 143).
+template <typename T, int FMT>
 __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoolP p) {
   typedef typename Elem<T>::frag frag;
   constexpr int W_BYTES = 7 * 64 * 64;
@@ -261,19 +264,22 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
   for (int i = wave; i < W_BYTES / 1024; i += 4) GLDS16((const char*)p.w + i * 1024 + lane * 16, Ws + i * 1024);
 
   // ---- staging geometry of this thread (tile independent): window column c, rows r0 + 6k
+  // every thread runs the loads (threads 252..255 repeat thread 251's: no divergent region around them), 252 store
   const bool stager = tid < 6 * PC;
-  const int r0 = tid / PC, c = tid - r0 * PC;
-  const int estep = p.in_format == 0 ? 1 : 3;
+  const int st = min(tid, 6 * PC - 1);
+  const int r0 = st / PC, c = st - r0 * PC;
+  constexpr int estep = FMT == 0 ? 1 : 3;
   const size_t img_elems = (size_t)3 * p.H * p.W;
   const int plane = p.H * p.W;
-  unsigned raw[NI][3];                              // the next tile's window as loaded (bit patterns), converted after the MFMAs
+  // the next tile's window exactly as the load instructions deliver it (f32: three dwords; 16-bit: one dword c0|c1 and one
+  // short c2; u8: one short c0|c1 and one byte c2) -- any unpacking here would have to wait for the loads, before the MFMAs
+  unsigned raw[NI][3];
   unsigned okmask = 0;
   auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {
     tx = tile % p.tiles_x; const int q = tile / p.tiles_x;
     ty = q % p.tiles_y; img = q / p.tiles_y;
   };
   auto issue_loads = [&](int tile) {
-    if (!stager) return;
     int tx, ty, img;
     tile_origin(tile, tx, ty, img);
     const int py0 = 2 * (2 * (ty * 8) - 1) - 3, px0 = 2 * (2 * (tx * 8) - 1) - 3;
@@ -288,41 +294,47 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
       if (okx && r < PR && y >= 0 && y < p.H) okmask |= 1u << k;
       off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;
     }
-    if (p.in_format == 0) {
+    if constexpr (FMT == 0) {
       const float* s = (const float*)p.x + (size_t)img * img_elems;
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
         raw[k][0] = __builtin_bit_cast(unsigned, s[off[k]]); raw[k][1] = __builtin_bit_cast(unsigned, s[off[k] + plane]);
         raw[k][2] = __builtin_bit_cast(unsigned, s[off[k] + 2 * plane]);
       }
-    } else if (p.in_format == 3) {
+    } else if constexpr (FMT == 3) {
       const unsigned char* s = (const unsigned char*)p.x + (size_t)img * img_elems;
 #pragma unroll
-      for (int k = 0; k < NI; ++k) { raw[k][0] = s[off[k]]; raw[k][1] = s[off[k] + 1]; raw[k][2] = s[off[k] + 2]; }
+      for (int k = 0; k < NI; ++k) {
+        unsigned short w01; __builtin_memcpy(&w01, s + off[k], 2);
+        raw[k][0] = w01; raw[k][1] = s[off[k] + 2];
+      }
     } else {
       const unsigned short* s = (const unsigned short*)p.x + (size_t)img * img_elems;
 #pragma unroll
-      for (int k = 0; k < NI; ++k) { raw[k][0] = s[off[k]]; raw[k][1] = s[off[k] + 1]; raw[k][2] = s[off[k] + 2]; }
+      for (int k = 0; k < NI; ++k) {
+        unsigned w01; __builtin_memcpy(&w01, s + off[k], 4);
+        raw[k][0] = w01; raw[k][1] = s[off[k] + 2];
+      }
     }
   };
   auto write_window = [&]() {
     if (!stager) return;
-    const bool same = (p.in_format == 1) == (sizeof(T) == 2 && std::is_same<T, bf16_t>::value);
+    constexpr bool same = (FMT == 1) == std::is_same<T, bf16_t>::value;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       u32x2 px;
-      if (p.in_format == 0)
+      if constexpr (FMT == 0)
         px = pack4<T>(__builtin_bit_cast(float, raw[k][0]), __builtin_bit_cast(float, raw[k][1]), __builtin_bit_cast(float, raw[k][2]));
-      else if (p.in_format == 3)
-        px = pack4<T>((float)raw[k][0] / 255.0f, (float)raw[k][1] / 255.0f, (float)raw[k][2] / 255.0f);
-      else if (same)
-        px = u32x2{raw[k][0] | (raw[k][1] << 16), raw[k][2]};
-      else if (p.in_format == 1)
-        px = pack4<T>(to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][0])), to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][1])),
-                      to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][2])));
+      else if constexpr (FMT == 3)
+        px = pack4<T>((float)(raw[k][0] & 0xffu) / 255.0f, (float)(raw[k][0] >> 8) / 255.0f, (float)raw[k][1] / 255.0f);
+      else if constexpr (same)
+        px = u32x2{raw[k][0], raw[k][1]};
+      else if constexpr (FMT == 1)
+        px = pack4<T>(to_f32(__builtin_bit_cast(bf16_t, (unsigned short)(raw[k][0] & 0xffffu))), to_f32(__builtin_bit_cast(bf16_t, (unsigned short)(raw[k][0] >> 16))),
+                      to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][1])));
       else
-        px = pack4<T>(to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][0])), to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][1])),
-                      to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][2])));
+        px = pack4<T>(to_f32(__builtin_bit_cast(f16_t, (unsigned short)(raw[k][0] & 0xffffu))), to_f32(__builtin_bit_cast(f16_t, (unsigned short)(raw[k][0] >> 16))),
+                      to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][1])));
       if (r0 + 6 * k < PR) *(u32x2*)(Ps + (tid + 6 * PC * k) * 8) = ((okmask >> k) & 1u) ? px : u32x2{0u, 0u};
     }
   };
@@ -428,10 +440,9 @@ extern "C" int flope_stem_pool_init() {
   hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)stem_pool_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#define PA(T_, F_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  PA(bf16_t, 0) PA(bf16_t, 1) PA(bf16_t, 2) PA(bf16_t, 3) PA(f16_t, 0) PA(f16_t, 1) PA(f16_t, 2) PA(f16_t, 3)
+#undef PA
   return (int)e;
 }
 
@@ -448,8 +459,10 @@ extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H
     const int total = B * p.tiles_y * p.tiles_x;
     const dim3 pgrid(persist_blocks < total ? persist_blocks : total);
     const size_t plds = 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16 + 17 * 17 * 128;
-    if (dtype == 0) hipLaunchKernelGGL(stem_pool_persist_kernel<bf16_t>, pgrid, block, plds, (hipStream_t)stream, p);
-    else            hipLaunchKernelGGL(stem_pool_persist_kernel<f16_t>, pgrid, block, plds, (hipStream_t)stream, p);
+#define PL(T_, F_) hipLaunchKernelGGL((stem_pool_persist_kernel<T_, F_>), pgrid, block, plds, (hipStream_t)stream, p)
+    if (dtype == 0) { if (in_format == 0) PL(bf16_t, 0); else if (in_format == 1) PL(bf16_t, 1); else if (in_format == 2) PL(bf16_t, 2); else PL(bf16_t, 3); }
+    else            { if (in_format == 0) PL(f16_t, 0); else if (in_format == 1) PL(f16_t, 1); else if (in_format == 2) PL(f16_t, 2); else PL(f16_t, 3); }
+#undef PL
     return (int)hipGetLastError();
   }
   const dim3 grid(B * p.tiles_y * p.tiles_x);
