@@ -471,7 +471,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value != 0; return prev; }
-  else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value != 0; return prev; }
+  else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
@@ -571,7 +571,11 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
   if (fused) {
     SMARK();
     K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w,
-                                                   e->stem_bias, bp.ptr, dt, e->opt_stem_persist ? 2 * e->num_cus : 0, stream));
+                                                   e->stem_bias, bp.ptr, dt,
+                                                   // persistent form where it measured faster (r02, same-run A/B at B = 256): 224 x 224 crops
+                                                   // +2.7 % on the step; 512 x 512 crops -7 % on the kernel.  1 = auto, 2 = always, 0 = never
+                                                   (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
+                                                   stream));
   } else {
     SMARK();
     K_TRY(e, "prep_input", flope_prep_input_launch(x, in_format, batch, e->H, e->W, stem_in, e->sHip, e->sWip, dt, stream));
