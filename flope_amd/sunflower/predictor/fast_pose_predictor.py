@@ -39,10 +39,19 @@ def select_boxes(boxes, frame_shape):
             np.array(good).astype(np.int16).reshape(-1, 4))
 
 
+def upload_depth(depth, dev):
+    """depth image -> device tensor (uint16 bits travel unchanged in an int16 tensor; anything else as float32 metres)"""
+    depth_np = np.ascontiguousarray(depth)
+    if depth_np.dtype == np.uint16:
+        return torch.from_numpy(depth_np.view(np.int16)).to(dev)
+    return torch.from_numpy(depth_np.astype(np.float32)).to(dev)
+
+
 def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_size=512, near=0.1, far=2.5,
-                          device=None, frame_d=None, mask_d=None):
+                          device=None, frame_d=None, mask_d=None, depth_d=None):
     """Shared tail of both predictors (fast_pose_predictor.py:65-156, pose_predictor.py:90-186).
-    frame_d / mask_d: the frame and the detector's mask when they are already on the device (the built-in detector)."""
+    frame_d / mask_d / depth_d: inputs that are already on the device (the built-in detector keeps frame and mask there
+    and uploads the depth image while the detector is still running)."""
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("flope_amd predictors run on HIP devices only")
@@ -53,11 +62,8 @@ def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_s
         frame_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
     if mask_d is None:
         mask_d = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(dev)
-    depth_np = np.ascontiguousarray(depth)
-    if depth_np.dtype == np.uint16:
-        depth_d = torch.from_numpy(depth_np.view(np.int16)).to(dev)        # bits travel unchanged
-    else:
-        depth_d = torch.from_numpy(depth_np.astype(np.float32)).to(dev)
+    if depth_d is None:
+        depth_d = upload_depth(depth, dev)
     K4 = (K[0][0], K[1][1], K[0][2], K[1][2])
     _, reliable, xyz = _engine.depth_lift(depth_d, mask_d, torch.from_numpy(good_bb.astype(np.int32)), K4,
                                           depth_div, near, far)
@@ -109,10 +115,11 @@ class FastPosePredictor:
         """rgb uint8 [H,W,3], depth uint16 [H,W] (millimetres) -> float64 [N,4,4] | None"""
         if self.yolo is not None:                  # frame and mask stay on the device between the detector and the crops
             det, count, mask_d, frame_d = self.yolo.detect_device(rgb)
+            depth_d = upload_depth(depth, torch.device(self.device))   # host copy runs while the GPU is busy with the detector
             n = int(count.item())
             bb = det[:n, :4].cpu().numpy().astype(np.int16)           # :55-56
             return poses_from_detections(self.posenet, rgb, depth, bb, None, self.K, depth_div=1000.0,
-                                         device=self.device, frame_d=frame_d, mask_d=mask_d)
+                                         device=self.device, frame_d=frame_d, mask_d=mask_d, depth_d=depth_d)
         bb, mask = self.get_bbox_mask(rgb)
         return poses_from_detections(self.posenet, rgb, depth, bb, mask, self.K, depth_div=1000.0,
                                      device=self.device)
