@@ -116,10 +116,12 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   const unsigned lane16 = lane * 16;
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
   const int wbase = 2 * PATCH_B + (wch * 64 + r16) * 64 + ((g ^ wsw) << 4);
-  const int cb = ntile * BN + wch * 64 + g * 16;
+  // this lane's channels: two runs of 8 (host_pack.h stag_row_to_channel): cb .. cb + 7 (accumulator tiles 0, 1) and
+  // cb + 32 .. cb + 39 (tiles 2, 3) -- byte offsets 16 g and 64 + 16 g inside the wave's 128-byte channel block
+  const int cb = ntile * BN + wch * 64 + g * 8;
   float bias[NT * 4];
 #pragma unroll
-  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
+  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + (i >> 3) * 32 + (i & 7)];
 
   // ---- tile geometry: wave-uniform part (first pixel, patch origin) and per-lane part (xoff, output offsets)
   int m0, mend, R0, mc0 = 0;                               // current tile (mc0: first output column, ROWS segments)
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       bool v_;
       const char* rp = (const char*)p.res + out_off(pt, v_);
       rpre[pt][0] = *(const u32x4*)rp;
-      rpre[pt][1] = *(const u32x4*)(rp + 16);
+      rpre[pt][1] = *(const u32x4*)(rp + 64);
     }
   }
   // ---- prologue: patch of this workgroup's first half-chunk, its double tiles 0 and 1
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                      \
         const char* rp_ = (const char*)p.res + rows_off(has_next ? n_m0 : m0, has_next ? n_mc0 : mc0, pt);     \
         rq[pt][0] = *(const u32x4*)rp_;                                                                        \
-        rq[pt][1] = *(const u32x4*)(rp_ + 16);                                                                 \
+        rq[pt][1] = *(const u32x4*)(rp_ + 64);                                                                 \
       }                                                                                                        \
     }                                                                                                          \
     /* ring: slot offsets fold into the ds_read immediates.  WRES: 72 KB of distinct offsets do not fit 16-bit     \
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         if (mm < mend) {
           float* wp = p.split_ws + ((size_t)ks * p.M + mm) * p.Cout + cb;
 #pragma unroll
-          for (int ct = 0; ct < NT; ++ct) *(f32x4*)(wp + ct * 4) = acc[pt][ct];
+          for (int ct = 0; ct < NT; ++ct) *(f32x4*)(wp + (ct >> 1) * 32 + (ct & 1) * 4) = acc[pt][ct];
         }
       }
     } else {
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
           for (int pt = 0; pt < MT; ++pt) {
             const char* rp = (const char*)p.res + ooff[pt];
             rv[pt][0] = *(const u32x4*)rp;
-            rv[pt][1] = *(const u32x4*)(rp + 16);
+            rv[pt][1] = *(const u32x4*)(rp + 64);
           }
         }
       }
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
               const unsigned w_ = pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]);
               o[q] = pk_out16<T>(w_, p.relu);                // ReLU (+ float16 saturation) on the packed pair
             }
-            *(u32x4*)(op + c * 16) = o;
+            *(u32x4*)(op + c * 64) = o;
           }
         }
 #pragma unroll
@@ -568,10 +570,10 @@ __global__ __launch_bounds__(512, 2) void conv_gstag_kernel(const ConvP p) {
   const unsigned lane16 = lane * 16;
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
   const int wbase = X_BYTES + (wch * 64 + r16) * 64 + ((g ^ wsw) << 4);
-  const int cb = ntile * 128 + wch * 64 + g * 16;
+  const int cb = ntile * 128 + wch * 64 + g * 8;           // two runs of 8 channels: cb.. and cb + 32.. (stag_row_to_channel)
   float bias[NT * 4];
 #pragma unroll
-  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + i];
+  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + (i >> 3) * 32 + (i & 7)];
   frag wf[2][NT], xf[2][MT];
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -636,7 +638,21 @@ __global__ __launch_bounds__(512, 2) void conv_gstag_kernel(const ConvP p) {
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) {
     const int m = m0 + group * GP + wpx * 64 + pt * 16 + pcol;
-    conv_epilogue_px<T, NT, false>(p, acc[pt], m, m < mend, cb, bias, HoWo);
+    if (m < mend) {                            // accumulators carry the bias; ReLU + pack; two 16-byte stores 64 bytes apart
+      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+      char* op = (char*)p.out + ((((size_t)b_ * p.Hop + ho_ + 1) * p.Wop + wo_ + 1) * p.Cout + cb) * 2;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = c * 8 + q * 2;
+          o[q] = pk_out16<T>(pack2<T>(acc[pt][i >> 2][i & 3], acc[pt][(i + 1) >> 2][(i + 1) & 3]), p.relu);
+        }
+        *(u32x4*)(op + c * 64) = o;
+      }
+    }
   }
   if (group == 0) G_BARRIER();                 // every wave executes the same number of barriers
   G_WAIT(0);                                   // drain the wrapped-around tail DMAs before LDS is released

@@ -84,8 +84,18 @@ inline std::vector<uint16_t> pack_conv(const std::vector<float>& wf, int cout, i
   return out;
 }
 
+// Row order of the conv_stag / conv_gstag images (r02).  Same idea as lds_row_to_channel, but a lane's 16 accumulators are TWO
+// runs of 8 consecutive channels, 32 channels apart: MFMA rows 4g..4g+3 of channel tile ct are channels
+// (ct >> 1) * 32 + 8 g + (ct & 1) * 4 .. + 3.  The epilogue's two 16-byte stores (and residual loads) of the four lane groups
+// of a pixel then cover bytes [0, 64) and [64, 128) of the pixel's 128-byte channel block contiguously -- 16 requests of 64 bytes
+// per wave-instruction instead of 64 pieces of 16 bytes at a 32-byte stride (measured: -1.5 ... -2.6 % per conv launch).
+inline int stag_row_to_channel(int rl) {
+  const int range = rl / 64, in = rl % 64, ct = in / 16, r = in % 16, g = r >> 2, q = r & 3;
+  return range * 64 + (ct >> 1) * 32 + g * 8 + (ct & 1) * 4 + q;
+}
+
 // conv_stag image: folded 3x3 weights wf[cout][cin][3][3] -> [ntile (cout/BN)][hc*9 + tap][BN rows][32 k], BN = min(cout,128),
-// 64-byte rows, 16-byte slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1}; rows permuted as in pack_conv
+// 64-byte rows, 16-byte slot g of row r at g ^ h[(r>>2)&3], h = {0,2,3,1}; rows permuted by stag_row_to_channel
 inline std::vector<uint16_t> pack_conv32(const std::vector<float>& wf, int cout, int cin, int dtype) {
   static const int h[4] = {0, 2, 3, 1};
   const int BN = cout == 64 ? 64 : 128, ntiles = cout / BN, nhc = cin / 32;
@@ -96,7 +106,7 @@ inline std::vector<uint16_t> pack_conv32(const std::vector<float>& wf, int cout,
         const size_t tile = ((size_t)nt * nhc * 9 + (size_t)hc * 9 + tap) * BN * 32;
         const int ky = tap / 3, kx = tap % 3;
         for (int rl = 0; rl < BN; ++rl) {
-          const int co = nt * BN + lds_row_to_channel(rl);
+          const int co = nt * BN + stag_row_to_channel(rl);
           for (int kk = 0; kk < 32; ++kk) {
             const float v = wf[(((size_t)co * cin + hc * 32 + kk) * 3 + ky) * 3 + kx];
             const int slot = (kk >> 3) ^ h[(rl >> 2) & 3];
@@ -116,7 +126,7 @@ inline std::vector<uint16_t> pack_conv32_1x1(const std::vector<float>& wf, int c
     for (int hc = 0; hc < nhc; ++hc) {
       const size_t tile = ((size_t)nt * nhc + hc) * BN * 32;
       for (int rl = 0; rl < BN; ++rl) {
-        const int co = nt * BN + lds_row_to_channel(rl);
+        const int co = nt * BN + stag_row_to_channel(rl);
         for (int kk = 0; kk < 32; ++kk) {
           const int slot = (kk >> 3) ^ h[(rl >> 2) & 3];
           out[tile + (size_t)rl * 32 + slot * 8 + (kk & 7)] = cvt16(wf[(size_t)co * cin + hc * 32 + kk], dtype);

@@ -31,6 +31,7 @@ void hh_cvt16(const float* src, uint16_t* dst, long n, int dtype) {
 }
 
 int hh_lds_row_to_channel(int rl) { return flope_host::lds_row_to_channel(rl); }
+int hh_stag_row_to_channel(int rl) { return flope_host::stag_row_to_channel(rl); }
 
 // packed conv image -> caller buffer (cout*cin*k*k uint16)
 void hh_pack_conv(const float* w, int cout, int cin, int k, int dtype, uint16_t* dst) {

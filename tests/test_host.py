@@ -172,6 +172,18 @@ def test_lds_row_permutation_is_a_bijection_with_consecutive_lane_channels(harne
             assert ch == list(range(rng_ * 64 + 16 * g, rng_ * 64 + 16 * g + 16))
 
 
+def test_stag_row_permutation_gives_two_runs_of_eight_channels_per_lane(harness):
+    """conv_stag / conv_gstag images: lane group g owns MFMA rows 4g..4g+3 of each of the 4 channel tiles = channels
+    8g..8g+7 (tiles 0, 1) and 32+8g..32+8g+7 (tiles 2, 3) of the wave's 64-channel range: the two 16-byte stores of a pixel's four
+    lane groups are contiguous 64-byte halves of its 128-byte channel block."""
+    rows = [harness.hh_stag_row_to_channel(r) for r in range(128)]
+    assert sorted(rows) == list(range(128))
+    for rng_ in range(2):
+        for g in range(4):
+            ch = [rows[rng_ * 64 + ct * 16 + 4 * g + q] for ct in range(4) for q in range(4)]
+            assert ch == list(range(rng_ * 64 + 8 * g, rng_ * 64 + 8 * g + 8)) + list(range(rng_ * 64 + 32 + 8 * g, rng_ * 64 + 40 + 8 * g))
+
+
 @pytest.mark.parametrize("cout,cin,k", [(64, 64, 3), (128, 64, 1), (256, 128, 3)])
 def test_pack_conv_is_a_permutation_of_the_weights(harness, cout, cin, k):
     n = cout * cin * k * k
