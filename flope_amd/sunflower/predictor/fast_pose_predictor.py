@@ -47,23 +47,18 @@ def upload_depth(depth, dev):
     return torch.from_numpy(depth_np.astype(np.float32)).to(dev)
 
 
-def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_size=512, near=0.1, far=2.5,
-                          device=None, frame_d=None, mask_d=None, depth_d=None):
-    """Shared tail of both predictors (fast_pose_predictor.py:65-156, pose_predictor.py:90-186).
-    frame_d / mask_d / depth_d: inputs that are already on the device (the built-in detector keeps frame and mask there
-    and uploads the depth image while the detector is still running)."""
+def enqueue_poses(posenet, frame_shape, boxes, K, depth_div, frame_d, mask_d, depth_d, crop_size=512, near=0.1, far=2.5,
+                  device=None):
+    """Device half of the shared tail of both predictors (fast_pose_predictor.py:65-144, pose_predictor.py:90-174): box
+    selection on the host, then depth lift, crops, PoseResNet, Procrustes, yaw-null and Rt assembly enqueued on the
+    current stream.  -> float32 [n, 17] on the device (16 pose entries + the depth-reliable flag) or None when no box
+    survives squarify / in-frame; nothing is synchronised."""
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("flope_amd predictors run on HIP devices only")
-    uv, sq_bb, good_bb = select_boxes(boxes, rgb.shape)
+    uv, sq_bb, good_bb = select_boxes(boxes, frame_shape)
     if good_bb.shape[0] == 0:
         return None
-    if frame_d is None:
-        frame_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
-    if mask_d is None:
-        mask_d = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(dev)
-    if depth_d is None:
-        depth_d = upload_depth(depth, dev)
     K4 = (K[0][0], K[1][1], K[0][2], K[1][2])
     _, reliable, xyz = _engine.depth_lift(depth_d, mask_d, torch.from_numpy(good_bb.astype(np.int32)), K4,
                                           depth_div, near, far)
@@ -77,11 +72,36 @@ def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_s
     crops = _engine.crop_resize_mask(frame_d, mask_d, sq_all, crop_size, fmt)
     _, R = posenet.predict_rotations(crops)
     Rt = _engine.compose_pose(R, xyz, nullify=True)
-    packed = torch.cat([Rt.reshape(-1, 16), reliable.to(torch.float32).reshape(-1, 1)], dim=1).cpu().numpy()
+    return torch.cat([Rt.reshape(-1, 16), reliable.to(torch.float32).reshape(-1, 1)], dim=1)
+
+
+def finish_poses(packed):
+    """Host half: one device -> host copy, drop the flowers without reliable depth (fast_pose_predictor.py:97-102),
+    float64 [N,4,4] or None (:86-87, :101-102)."""
+    if packed is None:
+        return None
+    packed = packed.cpu().numpy()
     keep = packed[:, 16] > 0.5
     if not keep.any():
         return None
     return packed[keep, :16].reshape(-1, 4, 4).astype(np.float64)
+
+
+def poses_from_detections(posenet, rgb, depth, boxes, mask, K, depth_div, crop_size=512, near=0.1, far=2.5,
+                          device=None, frame_d=None, mask_d=None, depth_d=None):
+    """Shared tail of both predictors (fast_pose_predictor.py:65-156, pose_predictor.py:90-186).
+    frame_d / mask_d / depth_d: inputs that are already on the device (the built-in detector keeps frame and mask there
+    and uploads the depth image while the detector is still running)."""
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise RuntimeError("flope_amd predictors run on HIP devices only")
+    if frame_d is None:
+        frame_d = torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev)
+    if mask_d is None:
+        mask_d = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(dev)
+    if depth_d is None:
+        depth_d = upload_depth(depth, dev)
+    return finish_poses(enqueue_poses(posenet, rgb.shape, boxes, K, depth_div, frame_d, mask_d, depth_d, crop_size, near, far, dev))
 
 
 class FastPosePredictor:
@@ -123,3 +143,51 @@ class FastPosePredictor:
         bb, mask = self.get_bbox_mask(rgb)
         return poses_from_detections(self.posenet, rgb, depth, bb, mask, self.K, depth_div=1000.0,
                                      device=self.device)
+
+    def iter_flower_poses(self, frames):
+        """`get_flower_poses` over a stream of (rgb, depth) frames, software-pipelined: the detector of frame t + 1 runs on
+        one HIP stream while crops -> PoseResNet -> Procrustes of frame t run on another (the detector is a chain of short
+        kernels that leaves most of the GPU idle; the pose network fills it).  Yields exactly what get_flower_poses returns,
+        frame by frame, in order; a result becomes available one frame late.  The reference loop (scripts/live_pose.py:31-41)
+        is sequential; this is the same computation with two frames in flight."""
+        if self.yolo is None:
+            for rgb, depth in frames:
+                yield self.get_flower_poses(rgb, depth)
+            return
+        dev = torch.device(self.device)
+        s_det, s_pose = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        H, W = self.yolo.frame_h, self.yolo.frame_w
+        copies = [(torch.empty((H, W, 3), dtype=torch.uint8, device=dev), torch.empty((H, W), dtype=torch.uint8, device=dev))
+                  for _ in range(2)]
+        pose_done = [None, None]               # pose stage finished reading copies[i]
+        pending, have_pending = None, False
+        for t, (rgb, depth) in enumerate(frames):
+            fb, mb = copies[t & 1]
+            with torch.cuda.stream(s_det):
+                det, count, mask_d, frame_d = self.yolo.detect_device(rgb)
+                if pose_done[t & 1] is not None:
+                    s_det.wait_event(pose_done[t & 1])
+                fb.copy_(frame_d, non_blocking=True)
+                mb.copy_(mask_d, non_blocking=True)
+                depth_d = upload_depth(depth, dev)
+                depth_d.record_stream(s_pose)
+                ready = torch.cuda.Event()
+                ready.record(s_det)
+            if have_pending:                   # frame t - 1: its device work overlapped the detector launched above
+                with torch.cuda.stream(s_pose):
+                    out = finish_poses(pending)
+                yield out
+            with torch.cuda.stream(s_det):
+                n = int(count.item())          # waits for the detector of frame t only
+                bb = det[:n, :4].cpu().numpy().astype(np.int16)
+            with torch.cuda.stream(s_pose):
+                s_pose.wait_event(ready)
+                pending = enqueue_poses(self.posenet, rgb.shape, bb, self.K, 1000.0, fb, mb, depth_d, device=dev)
+                have_pending = True
+                ev = torch.cuda.Event()
+                ev.record(s_pose)
+                pose_done[t & 1] = ev
+        if have_pending:
+            with torch.cuda.stream(s_pose):
+                out = finish_poses(pending)
+            yield out

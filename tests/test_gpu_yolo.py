@@ -206,6 +206,36 @@ def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path
     assert (np.logical_xor(mask > 127, rmask > 127)).mean() < 0.02
 
 
+def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path):
+    """FastPosePredictor.iter_flower_poses (detector of frame t + 1 on one stream beside the pose network of frame t on
+    another, double-buffered frame / mask copies) returns, frame by frame, exactly what get_flower_poses returns."""
+    import yaml
+    from flope_amd.harness import live_pose_loop
+    from flope_amd.yolo_weights import synthetic_frame
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor
+    H, W = 540, 960
+    yolo_f, ckpt, intr = tmp_path / "yolo.pth", tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save({**ysd, "imgsz": torch.tensor(640)}, yolo_f)
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=700.0, fy=700.0, cx=W / 2, cy=H / 2, h=H, w=W)))
+    pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr))
+    rng = np.random.default_rng(3)
+    frames = []
+    for i in range(5):
+        img = synthetic_frame(20 + i, H, W)
+        depth = (400 + rng.normal(0, 4, (H, W))).astype(np.uint16)
+        if i == 2:
+            img = np.zeros_like(img)                  # a frame with nothing to detect in the middle of the stream
+        frames.append((img, depth))
+    seq = live_pose_loop(pred, frames)
+    pip = live_pose_loop(pred, frames, pipelined=True)
+    assert len(seq) == len(pip) == 5 and any(r is not None for r in seq)
+    for a, b in zip(seq, pip):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a, b)
+
+
 def test_yolo_error_paths(ysd):
     from flope_amd.yolo import YoloSeg
     with pytest.raises(RuntimeError, match="imgsz"):
