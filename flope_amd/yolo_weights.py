@@ -101,14 +101,15 @@ def conv_specs(widths=(16, 32, 64, 128, 256), nc: int = 1, nm: int = 32):
     return out
 
 
-def synthetic_yolo_state_dict(seed: int = 0, nc: int = 1, cls_bias: float = -4.5) -> dict:
-    """Seeded random-init yolo11n-seg ``state_dict`` (CPU generator: identical on every machine).
+def synthetic_yolo_state_dict(seed: int = 0, nc: int = 1, cls_bias: float = -4.5, widths=(16, 32, 64, 128, 256)) -> dict:
+    """Seeded random-init yolo11n-seg ``state_dict`` (CPU generator: identical on every machine; ``widths`` =
+    (32, 64, 128, 256, 512) gives the ``s`` scale).
     He-scaled convolutions, non-trivial BatchNorm statistics, and a class-head bias that lets a small
     fraction of the anchors pass the default 0.25 confidence threshold on a noise frame."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     sd = {}
-    for p, kind, cout, cin, k, groups in conv_specs(nc=nc):
+    for p, kind, cout, cin, k, groups in conv_specs(widths=widths, nc=nc):
         fan_in = cin * k * k
         if kind == "conv":
             # linear (act=False) convs and the closing conv of a residual branch get a smaller gain: nothing

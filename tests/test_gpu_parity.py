@@ -573,3 +573,35 @@ def test_rotation_error_vs_conditioning_of_M(state_dict, dtype):
         assert k <= 2.5 * dM + 1e-6, (a, k, dM)
         if gmin >= (0.5 if dtype == "f16" else 3 * dM / 1e-3):
             assert dR <= 1e-3, (a, gmin, dR)
+
+
+def test_float16_activations_saturate_instead_of_overflowing(state_dict):
+    """a checkpoint whose residual stream outgrows the float16 range must not turn into inf -> NaN -> a garbage
+    rotation.  Scaling one BatchNorm's gamma by 3e4 pushes layer1.0 beyond 65504: the 16-bit epilogues saturate at
+    +-65504 (v_pk_min_f16), every later stage stays finite, and the rotation is still a rotation."""
+    sd = dict(state_dict)
+    sd["base.layer1.0.bn2.weight"] = state_dict["base.layer1.0.bn2.weight"] * 3e4
+    torch.manual_seed(3)
+    x = torch.rand(3, 3, 224, 224)
+    e = _engine(sd, 224, 224, 3, "f16")
+    r9, R = _run(e, x)
+    l10 = e.read_stage("layer1.0", 3).cpu()
+    assert torch.isfinite(l10).all() and float(l10.max()) == 65504.0
+    assert torch.isfinite(r9).all() and torch.isfinite(R).all()
+    assert (R @ R.transpose(1, 2) - torch.eye(3)).abs().max() < 1e-4 and (torch.linalg.det(R) - 1).abs().max() < 1e-4
+    e.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_engine_on_the_second_device_while_the_first_is_current(state_dict):
+    """the forward selects the handle's device itself (hipSetDevice in run_trunk / read_stage)."""
+    torch.manual_seed(4)
+    x = torch.rand(2, 3, 96, 96)
+    from flope_amd.engine import PoseEngine
+    e = PoseEngine(96, 96, 2, "f16", device="cuda:1")
+    e.load_state_dict(state_dict)
+    torch.cuda.set_device(0)
+    r9, R = e.forward(x.to("cuda:1"))
+    ref = O.procrustes_to_rotmat(O.forward(state_dict, x))
+    assert R.device.index == 1 and (R.cpu() - ref).abs().max() <= 1e-3
+    e.close()

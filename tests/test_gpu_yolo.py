@@ -206,6 +206,29 @@ def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path
     assert (np.logical_xor(mask > 127, rmask > 127)).mean() < 0.02
 
 
+@pytest.mark.parametrize("widths,nc,seed,H,W,imgsz", [((16, 32, 64, 128, 256), 3, 1, 360, 640, 640), ((32, 64, 128, 256, 512), 1, 0, 300, 500, 320),
+                                                       ((32, 64, 128, 256, 512), 2, 0, 1080, 1920, 640)])
+def test_other_checkpoints_scale_s_and_several_classes(widths, nc, seed, H, W, imgsz):
+    """The graph is built from the checkpoint: the `s` scale (twice the widths, four attention heads in C2PSA) and
+    multi-class heads (class-aware NMS through the cls * 7680 box offset) need no code path of their own."""
+    from flope_amd.yolo_weights import synthetic_frame, synthetic_yolo_state_dict
+    sd = synthetic_yolo_state_dict(seed, nc=nc, widths=widths, cls_bias=-3.0)
+    img = synthetic_frame(11, H, W)
+    y = _engine(sd, H, W, imgsz)
+    boxes, sc, cls, anchor, mask = y.detect(img, 0.05, 0.6)
+    o = Y.forward_layers(sd, Y.preprocess(img, imgsz))
+    for name in ("10", "16", "22"):
+        assert _rel(y.read_tensor(name).cpu(), o[int(name)][0]) <= 1.5e-2, name
+    assert _rel(y.read_tensor("proto").cpu(), o["proto"][0]) <= 3e-2
+    pred = Y.decode(_head_rows(y)).numpy()
+    det, idx = Y.non_max_suppression(pred, nc, 0.05, 0.6)
+    assert anchor.tolist() == idx.tolist() and len(idx) >= 3
+    assert cls.tolist() == det[:, 5].astype(int).tolist()
+    if nc > 1:
+        assert len(set(cls.tolist())) >= 2
+    y.close()
+
+
 def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path):
     """FastPosePredictor.iter_flower_poses (detector of frame t + 1 on one stream beside the pose network of frame t on
     another, double-buffered frame / mask copies) returns, frame by frame, exactly what get_flower_poses returns."""
