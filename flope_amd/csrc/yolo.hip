@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void yread_kernel(const void* src, int kind, i
     const size_t r = i / W;
     const int y = (int)(r % H), c = (int)(r / H);
     const size_t s = ((size_t)y * W + x) * ld + c;
-    dst[i] = kind == 1 ? ((const float*)src)[s] : (kind == 2 ? (float)((const uint8_t*)src)[s] : to_f32<T>(((const T*)src)[s]));
+    dst[i] = kind == 1 ? ((const float*)src)[s] : (kind == 2 ? (float)((const uint8_t*)src)[s] : (kind == 3 ? (float)((const int*)src)[s] : to_f32<T>(((const T*)src)[s])));
   }
 }
 

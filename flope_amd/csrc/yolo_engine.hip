@@ -611,6 +611,12 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
   {
     Tap t; t.is_f32 = 2; t.ptr = e->merged; t.H = h; t.W = w; t.C = 1; t.ld = 1;
     e->taps["mask_lb"] = t;
+    Tap c; c.is_f32 = 1; c.ptr = d.cand_box; c.H = 1; c.W = e->A; c.C = 4; c.ld = 4;
+    e->taps["cand_box"] = c;                        // decoded xyxy of every anchor (letterbox pixels), after flope_yolo_detect
+    c.ptr = d.cand_conf; c.C = 1; c.ld = 1;
+    e->taps["cand_conf"] = c;                       // best class confidence of every anchor
+    c.is_f32 = 3; c.ptr = d.cand_cls;
+    e->taps["cand_cls"] = c;                        // its class index
   }
   YLetterP& L = e->letter; memset(&L, 0, sizeof L);
   L.H = e->H; L.W = e->W; L.out = e->tensors[x].ptr; L.h = h; L.w = w; L.nh = e->nh; L.nw = e->nw; L.top = e->top; L.left = e->left;

@@ -226,7 +226,8 @@ int flope_yolo_detect(flope_yolo_handle h, const uint8_t* frame_dev, float conf,
 int flope_yolo_forward(flope_yolo_handle h, const uint8_t* frame_dev, void* stream);
 /* copy one map of the LAST forward to float32 [C,H,W]: "input", graph outputs "0".."22" (yaml indices of Conv / C3k2 /
  * SPPF / C2PSA modules), "box0..2" / "cls0..2" / "coef0..2" (Segment head rows per level), "proto", "proto_up",
- * "mask_lb" (merged mask at the letterboxed size, after flope_yolo_detect).  dims_out[3] = {C,H,W}; dst_dev NULL = size
+ * "mask_lb" (merged mask at the letterboxed size), "cand_box" [4,1,A] / "cand_conf" / "cand_cls" [1,1,A] (decoded box, best
+ * confidence and class of every anchor) -- the last four after flope_yolo_detect.  dims_out[3] = {C,H,W}; dst_dev NULL = size
  * query only. */
 int flope_yolo_read_tensor(flope_yolo_handle h, const char* name, float* dst_dev, int64_t* dims_out, void* stream);
 /* runtime knobs (A/B variants inside one build; each returns the previous value or <0):

@@ -185,24 +185,36 @@ def nms_numpy(boxes, scores, iou_thres):
     return np.array(keep, np.int64)
 
 
+def candidates(pred, nc):
+    """First half of ops.non_max_suppression for one image: xywh2xyxy, best class per anchor.
+    -> (box float32 [A,4] xyxy, conf float32 [A], cls int64 [A])"""
+    pred = np.asarray(pred, np.float32)
+    xy, wh = pred[:, :2], pred[:, 2:4] / np.float32(2)
+    box = np.concatenate([xy - wh, xy + wh], 1).astype(np.float32)
+    return box, pred[:, 4:4 + nc].max(1), pred[:, 4:4 + nc].argmax(1)
+
+
+def nms_candidates(box, conf, cls, conf_thres=0.25, iou_thres=0.7, max_det=300, max_wh=7680, max_nms=30000):
+    """Second half: confidence filter (anchor order kept), class-offset boxes, torchvision-style NMS, max_det.
+    -> kept anchor indices in NMS order."""
+    idx = np.nonzero(conf > np.float32(conf_thres))[0]
+    if idx.shape[0] == 0:
+        return idx
+    if idx.shape[0] > max_nms:
+        idx = idx[np.argsort(-conf[idx], kind="stable")[:max_nms]]
+    off = (cls[idx].astype(np.float32) * np.float32(max_wh))[:, None]
+    keep = nms_numpy(box[idx] + off, conf[idx], iou_thres)[:max_det]
+    return idx[keep]
+
+
 def non_max_suppression(pred, nc, conf_thres=0.25, iou_thres=0.7, max_det=300, max_wh=7680, max_nms=30000):
     """ops.non_max_suppression for one image, single label per box.  pred [A, 4+nc+32] as `decode` returns.
     -> (det float32 [n, 6 + 32]: xyxy, conf, cls, coefficients; anchor indices [n])"""
     pred = np.asarray(pred, np.float32)
-    idx = np.nonzero(pred[:, 4:4 + nc].max(1) > np.float32(conf_thres))[0]
-    x = pred[idx]
-    if x.shape[0] == 0:
-        return np.zeros((0, 6 + NM), np.float32), idx
-    xy, wh = x[:, :2], x[:, 2:4] / np.float32(2)
-    box = np.concatenate([xy - wh, xy + wh], 1).astype(np.float32)
-    conf = x[:, 4:4 + nc].max(1)
-    j = x[:, 4:4 + nc].argmax(1).astype(np.float32)
-    x = np.concatenate([box, conf[:, None], j[:, None], x[:, 4 + nc:]], 1)
-    if x.shape[0] > max_nms:
-        o = np.argsort(-x[:, 4], kind="stable")[:max_nms]
-        x, idx = x[o], idx[o]
-    keep = nms_numpy(x[:, :4] + x[:, 5:6] * np.float32(max_wh), x[:, 4], iou_thres)[:max_det]
-    return x[keep], idx[keep]
+    box, conf, cls = candidates(pred, nc)
+    keep = nms_candidates(box, conf, cls, conf_thres, iou_thres, max_det, max_wh, max_nms)
+    det = np.concatenate([box[keep], conf[keep, None], cls[keep, None].astype(np.float32), pred[keep, 4 + nc:]], 1).astype(np.float32)
+    return det.reshape(-1, 6 + NM), keep
 
 
 def process_mask(proto, coef, boxes, shape):

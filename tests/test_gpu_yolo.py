@@ -104,25 +104,40 @@ def _head_rows(y):
                                                         (1080, 1920, 1280, 0.02, 0.7, 17), (360, 640, 640, 0.03, 0.7, 300),
                                                         (360, 640, 640, 0.9999, 0.7, 300)])
 def test_decode_nms_boxes_bit_exact_given_the_head_rows(ysd, H, W, imgsz, conf, iou, max_det):
-    """Detect._inference + ops.non_max_suppression + ops.scale_boxes on the device against the numpy restatement fed
-    with the SAME float32 head rows: kept anchors and their order identical, boxes / scores to float32 round-off."""
+    """Detect._inference + ops.non_max_suppression + ops.scale_boxes on the device against the numpy restatement.
+    Decode (DFL expectation, dist2bbox, sigmoid) from the SAME float32 head rows: to float32 round-off.  NMS from the
+    device's own decoded candidates: kept anchors and their order IDENTICAL (integer / index work: bit-exact) -- two
+    confidences one ulp apart may legitimately sort either way, so the index test must not depend on whose exp() it was."""
     from flope_amd.yolo_weights import synthetic_frame
     img = synthetic_frame(4, H, W)
     y = _engine(ysd, H, W, imgsz)
     boxes, sc, cls, anchor, mask = y.detect(img, conf, iou, max_det)
-    pred = Y.decode(_head_rows(y)).numpy()
-    det, idx = Y.non_max_suppression(pred, 1, conf, iou, max_det)
-    assert anchor.tolist() == idx.tolist(), (len(anchor), len(idx))
+    _check_decode_and_nms(y, img, 1, conf, iou, max_det, boxes, sc, cls, anchor)
     if conf < 0.9:
-        assert len(idx) >= (8 if max_det > 17 else 17)
+        assert len(anchor) >= (8 if max_det > 17 else 17)
     else:
-        assert len(idx) == 0 and not mask.any()
-    if len(idx):
-        np.testing.assert_allclose(sc, det[:, 4], rtol=2e-6)
-        ref_boxes = Y.scale_boxes(y.input_hw, det[:, :4], img.shape)
-        np.testing.assert_allclose(boxes, ref_boxes, atol=2e-3)
-        assert (cls == 0).all() and (np.diff(sc) <= 0).all()
+        assert len(anchor) == 0 and not mask.any()
     y.close()
+
+
+def _check_decode_and_nms(y, img, nc, conf, iou, max_det, boxes, sc, cls, anchor):
+    pred = Y.decode(_head_rows(y)).numpy()
+    rbox, rconf, rcls = Y.candidates(pred, nc)
+    cbox = y.read_tensor("cand_box").cpu().numpy()[:, 0].T
+    cconf = y.read_tensor("cand_conf").cpu().numpy()[0, 0]
+    ccls = y.read_tensor("cand_cls").cpu().numpy()[0, 0].astype(np.int64)
+    np.testing.assert_allclose(cconf, rconf, rtol=3e-6)
+    np.testing.assert_allclose(cbox, rbox, atol=2e-3)
+    sure = np.abs(pred[:, 4:4 + nc].max(1) - np.sort(pred[:, 4:4 + nc], 1)[:, -2 if nc > 1 else -1]) > 1e-5 if nc > 1 else np.ones(len(rcls), bool)
+    assert (ccls == rcls)[sure].all()
+    keep = Y.nms_candidates(cbox, cconf, ccls, conf, iou, max_det)
+    assert anchor.tolist() == keep.tolist(), (len(anchor), len(keep))
+    if len(keep):
+        assert np.array_equal(sc, cconf[keep]) and np.array_equal(cls, ccls[keep]) and (np.diff(sc) <= 0).all()
+        np.testing.assert_allclose(boxes, Y.scale_boxes(y.input_hw, cbox[keep], img.shape), atol=1e-4)
+    # and against the all-oracle pipeline: the same detections unless two candidates are within round-off of each other
+    det, idx = Y.non_max_suppression(pred, nc, conf, iou, max_det)
+    assert len(set(idx.tolist()) ^ set(keep.tolist())) <= max(2, len(keep) // 20)
 
 
 def test_masks_vs_oracle_given_the_head_rows(ysd):
@@ -220,10 +235,8 @@ def test_other_checkpoints_scale_s_and_several_classes(widths, nc, seed, H, W, i
     for name in ("10", "16", "22"):
         assert _rel(y.read_tensor(name).cpu(), o[int(name)][0]) <= 1.5e-2, name
     assert _rel(y.read_tensor("proto").cpu(), o["proto"][0]) <= 3e-2
-    pred = Y.decode(_head_rows(y)).numpy()
-    det, idx = Y.non_max_suppression(pred, nc, 0.05, 0.6)
-    assert anchor.tolist() == idx.tolist() and len(idx) >= 3
-    assert cls.tolist() == det[:, 5].astype(int).tolist()
+    _check_decode_and_nms(y, img, nc, 0.05, 0.6, 300, boxes, sc, cls, anchor)
+    assert len(anchor) >= 3
     if nc > 1:
         assert len(set(cls.tolist())) >= 2
     y.close()
