@@ -59,12 +59,11 @@ struct YDecodeP {
   float* cand_box;                           // [A][4] xyxy (letterbox pixels)
   float* cand_conf;                          // [A]
   int* cand_cls;                             // [A]
-  int* cand_list; int* cand_count; int cand_cap;   // anchors that pass the confidence threshold (unordered)
 };
 
 struct YNmsP {
   const float* cand_box; const float* cand_conf; const int* cand_cls;
-  const int* cand_list; const int* cand_count; int cand_cap;
+  int A; float conf;                         // candidates = anchors with confidence > conf (the kNmsCap most confident ones)
   float iou; int max_det; float max_wh;
   // letterbox -> frame (ops.scale_boxes): x = (x - pad_x) / gain clipped to [0, W]
   float pad_x, pad_y, gain; int frame_w, frame_h;

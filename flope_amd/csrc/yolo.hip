@@ -486,10 +486,6 @@ __global__ __launch_bounds__(256) void ydecode_kernel(const YDecodeP p) {
   }
   p.cand_conf[a] = best;
   p.cand_cls[a] = bj;
-  if (best > p.conf) {
-    const int slot = atomicAdd(p.cand_count, 1);
-    if (slot < p.cand_cap) p.cand_list[slot] = a;
-  }
 }
 
 // ops.non_max_suppression (single label per box) + torchvision.ops.nms, one workgroup:
@@ -503,15 +499,73 @@ __global__ __launch_bounds__(1024) void ynms_kernel(const YNmsP p) {
   __shared__ float sbox[kNmsCap][4];
   __shared__ float sarea[kNmsCap];
   __shared__ unsigned char dead[kNmsCap];
+  __shared__ int sscan[1024];
   __shared__ int kept_n;
   const int tid = threadIdx.x;
-  int n = min(min(*p.cand_count, p.cand_cap), kNmsCap);
+  // ---- candidates: every anchor whose confidence passes the threshold, gathered in anchor order (no atomics: the set and
+  // its order are deterministic).  More than kNmsCap of them (a threshold far below ultralytics' 0.25 default): the kNmsCap
+  // most confident ones -- a bisection on the float bit pattern finds the cut, ties at the cut enter in anchor order
+  // (ultralytics keeps the 30,000 most confident; documented deviation for 4,096 < n <= 30,000).
+  const int chunk = (p.A + 1023) / 1024, a0 = min(tid * chunk, p.A), a1 = min(a0 + chunk, p.A);
+  auto block_scan = [&](int v, int* total) {        // inclusive scan of v over the 1024 threads -> exclusive prefix
+    sscan[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = tid >= off ? sscan[tid - off] : 0;
+      __syncthreads();
+      sscan[tid] += t;
+      __syncthreads();
+    }
+    *total = sscan[1023];
+    const int ex = sscan[tid] - v;
+    __syncthreads();
+    return ex;
+  };
+  auto count_above = [&](unsigned tb) {
+    int c = 0;
+    for (int a = a0; a < a1; ++a) { const float v = p.cand_conf[a]; c += (v > p.conf && __float_as_uint(v) > tb) ? 1 : 0; }
+    return c;
+  };
+  unsigned cut = 0;                                  // candidates: conf > p.conf and bits(conf) > cut (+ ties at the cut)
+  int total;
+  int ex = block_scan(count_above(0u), &total);
+  int n_eq_take = 0;
+  if (total > kNmsCap) {
+    unsigned lo = 0u, hi = 0x3f800000u;              // confidences are sigmoids in (0, 1): bit order = value order
+    while (lo < hi) {                                // smallest cut with count(bits > cut) <= kNmsCap
+      const unsigned mid = lo + ((hi - lo) >> 1);
+      int t2;
+      block_scan(count_above(mid), &t2);
+      if (t2 <= kNmsCap) hi = mid; else lo = mid + 1;
+    }
+    cut = lo;
+    ex = block_scan(count_above(cut), &total);
+    n_eq_take = kNmsCap - total;                     // free slots for confidences exactly at the cut
+  }
+  int n = total;
+  {
+    int w = ex;
+    for (int a = a0; a < a1; ++a) {
+      const float v = p.cand_conf[a];
+      if (v > p.conf && __float_as_uint(v) > cut) { sanc[w] = a; sconf[w] = v; ++w; }
+    }
+  }
+  if (n_eq_take > 0) {
+    int c = 0;
+    for (int a = a0; a < a1; ++a) { const float v = p.cand_conf[a]; c += (v > p.conf && __float_as_uint(v) == cut) ? 1 : 0; }
+    int teq;
+    const int exq = block_scan(c, &teq);
+    int w = exq;
+    for (int a = a0; a < a1; ++a) {
+      const float v = p.cand_conf[a];
+      if (v > p.conf && __float_as_uint(v) == cut) { if (w < n_eq_take) { sanc[n + w] = a; sconf[n + w] = v; } ++w; }
+    }
+    n += min(teq, n_eq_take);
+  }
+  __syncthreads();
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
-  for (int i = tid; i < np2; i += 1024) {
-    if (i < n) { const int a = p.cand_list[i]; sanc[i] = a; sconf[i] = p.cand_conf[a]; }
-    else { sanc[i] = 0x7fffffff; sconf[i] = -1.f; }
-  }
+  for (int i = n + tid; i < np2; i += 1024) { sanc[i] = 0x7fffffff; sconf[i] = -1.f; }
   if (tid == 0) kept_n = 0;
   __syncthreads();
   for (int k = 2; k <= np2; k <<= 1)

@@ -587,13 +587,11 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
     e->owned.push_back(p);
     return p;
   };
-  const int cap = std::min(e->A, 4096);
   YDecodeP& d = e->dec;
   d.pred = e->pred; d.A = e->A; d.no = e->no; d.nc = e->nc; d.conf = 0.25f;
   d.cand_box = (float*)dalloc((size_t)e->A * 16); d.cand_conf = (float*)dalloc((size_t)e->A * 4); d.cand_cls = (int*)dalloc((size_t)e->A * 4);
-  d.cand_list = (int*)dalloc((size_t)cap * 4); d.cand_count = (int*)dalloc(64); d.cand_cap = cap;
   YNmsP& q = e->nms; memset(&q, 0, sizeof q);
-  q.cand_box = d.cand_box; q.cand_conf = d.cand_conf; q.cand_cls = d.cand_cls; q.cand_list = d.cand_list; q.cand_count = d.cand_count; q.cand_cap = cap;
+  q.cand_box = d.cand_box; q.cand_conf = d.cand_conf; q.cand_cls = d.cand_cls; q.A = e->A;
   q.max_wh = 7680.f;
   // ops.scale_boxes(img1_shape = letterboxed, boxes, img0_shape = frame): gain, pad with python's round()
   {
@@ -642,11 +640,9 @@ static int detect_body(flope_yolo* e, const uint8_t* frame_dev, float conf, floa
                        int32_t* count_dev, uint8_t* mask_dev, void* stream) {
   int rc = flope_yolo_forward(e, frame_dev, stream);
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  Y_TRY(e, hipMemsetAsync(e->dec.cand_count, 0, 4, st));
   YDecodeP d = e->dec; d.conf = conf;
   int s = flope_ydecode_launch(&d, stream);
-  YNmsP q = e->nms; q.iou = iou; q.max_det = max_det; q.det = det_dev; q.det_count = count_dev;
+  YNmsP q = e->nms; q.conf = conf; q.iou = iou; q.max_det = max_det; q.det = det_dev; q.det_count = count_dev;
   if (!s) s = flope_ynms_launch(&q, stream);
   YMaskP m = e->mask; m.det_count = count_dev; m.max_det = max_det;
   if (!s) s = flope_ymask_launch(&m, e->dtype, stream);
@@ -712,4 +708,4 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
 }
 
 extern "C" double flope_yolo_flops(flope_yolo_handle e) { return e ? e->flops : 0.0; }
-extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->ops.size() + 6 : 0; }
+extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->ops.size() + 6 : 0; }   // + letterbox, decode, nms, 2 mask kernels, resize

@@ -216,7 +216,8 @@ int flope_yolo_input_size(flope_yolo_handle h, int* in_h, int* in_w);
 int flope_yolo_load_weights(flope_yolo_handle h, int n, const char* const* names,
                             const float* const* host_ptrs, const int* ndims, const int64_t* const* shapes);
 /* `results = self.yolo(image)` + get_bbox_mask's post-processing.  frame_dev: uint8 BGR [H,W,3] (a cv2 image).
- * conf / iou / max_det: ultralytics predict defaults are 0.25 / 0.7 / 300 (max_det <= 300).
+ * conf / iou / max_det: ultralytics predict defaults are 0.25 / 0.7 / 300 (max_det <= 300).  NMS considers the 4,096 most
+ * confident anchors above `conf` (ultralytics: 30,000) -- identical unless more than 4,096 anchors pass the threshold.
  * det_dev float32 [max_det,8]: rows = xyxy in frame pixels (ops.scale_boxes, clipped; the reference casts them to
  * int16), confidence, class, anchor index, 0 -- in NMS order; count_dev int32 [1]; mask_dev uint8 [H,W] = the summed /
  * clipped / x255 instance masks resized to the frame with cv2's 8-bit INTER_LINEAR (fast_pose_predictor.py:50-54). */

@@ -196,12 +196,13 @@ def candidates(pred, nc):
 
 def nms_candidates(box, conf, cls, conf_thres=0.25, iou_thres=0.7, max_det=300, max_wh=7680, max_nms=30000):
     """Second half: confidence filter (anchor order kept), class-offset boxes, torchvision-style NMS, max_det.
-    -> kept anchor indices in NMS order."""
+    -> kept anchor indices in NMS order.  max_nms: ultralytics keeps the 30,000 most confident candidates; the device
+    path keeps 4,096 (pass max_nms=4096 to restate it: the most confident ones, ties at the cut in anchor order)."""
     idx = np.nonzero(conf > np.float32(conf_thres))[0]
     if idx.shape[0] == 0:
         return idx
     if idx.shape[0] > max_nms:
-        idx = idx[np.argsort(-conf[idx], kind="stable")[:max_nms]]
+        idx = np.sort(idx[np.argsort(-conf[idx], kind="stable")[:max_nms]])
     off = (cls[idx].astype(np.float32) * np.float32(max_wh))[:, None]
     keep = nms_numpy(box[idx] + off, conf[idx], iou_thres)[:max_det]
     return idx[keep]

@@ -130,14 +130,15 @@ def _check_decode_and_nms(y, img, nc, conf, iou, max_det, boxes, sc, cls, anchor
     np.testing.assert_allclose(cbox, rbox, atol=2e-3)
     sure = np.abs(pred[:, 4:4 + nc].max(1) - np.sort(pred[:, 4:4 + nc], 1)[:, -2 if nc > 1 else -1]) > 1e-5 if nc > 1 else np.ones(len(rcls), bool)
     assert (ccls == rcls)[sure].all()
-    keep = Y.nms_candidates(cbox, cconf, ccls, conf, iou, max_det)
+    keep = Y.nms_candidates(cbox, cconf, ccls, conf, iou, max_det, max_nms=4096)     # the device's candidate capacity
     assert anchor.tolist() == keep.tolist(), (len(anchor), len(keep))
     if len(keep):
         assert np.array_equal(sc, cconf[keep]) and np.array_equal(cls, ccls[keep]) and (np.diff(sc) <= 0).all()
         np.testing.assert_allclose(boxes, Y.scale_boxes(y.input_hw, cbox[keep], img.shape), atol=1e-4)
     # and against the all-oracle pipeline: the same detections unless two candidates are within round-off of each other
-    det, idx = Y.non_max_suppression(pred, nc, conf, iou, max_det)
-    assert len(set(idx.tolist()) ^ set(keep.tolist())) <= max(2, len(keep) // 20)
+    if int((cconf > conf).sum()) <= 4096:
+        det, idx = Y.non_max_suppression(pred, nc, conf, iou, max_det)
+        assert len(set(idx.tolist()) ^ set(keep.tolist())) <= max(2, len(keep) // 20)
 
 
 def test_masks_vs_oracle_given_the_head_rows(ysd):
