@@ -24,6 +24,7 @@ python tools/summarize_prof.py $OUT/kt $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
 python tools/summarize_prof.py $OUT/calib > $OUT/calib_summary.txt
 python tools/roofline_table.py $OUT > $OUT/roofline.md
 python tools/make_traffic_json.py $OUT > $OUT/traffic.json
+cp $OUT/traffic.json profiles/r02_traffic.json      # bench.py reads the committed file: same sources, same digest
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 16
 echo "bench done"
 python tools/bench_e2e.py yolo 4 16 31 > $OUT/e2e.txt 2>&1
