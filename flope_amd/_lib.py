@@ -51,6 +51,7 @@ SIGNATURES = {
     "flope_yolo_forward": (_I, [_P, _P, _P]),
     "flope_yolo_read_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _P]),
     "flope_yolo_set_option": (_I, [_P, C.c_char_p, _I]),
+    "flope_yolo_profile": (_I, [_P, _P, _I, C.c_char_p, _I, _P]),
     "flope_yolo_flops": (_D, [_P]),
     "flope_yolo_launches": (_I, [_P]),
     "flope_tf_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),

@@ -707,5 +707,58 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
 }
 
+// Developer aid: `iters` forwards with a HIP event pair around every launch of the graph; text table of the mean microseconds
+// per launch (name, kind, geometry) into text_out.  Serialises nothing but the stream it is given.
+extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev, int iters, char* text_out, int cap, void* stream) {
+  if (!e || !frame_dev || !text_out || cap < 64 || iters < 1) return yfail(e, FLOPE_EINVAL, "flope_yolo_profile: bad argument");
+  if (!e->loaded) return yfail(e, FLOPE_ESTATE, "flope_yolo_profile before flope_yolo_load_weights");
+  Y_TRY(e, hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = e->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& x : ev) Y_TRY(e, hipEventCreate(&x));
+  std::vector<double> us(n, 0.0);
+  int rc = FLOPE_OK;
+  for (int it = 0; it < iters + 1 && !rc; ++it) {
+    YLetterP L = e->letter; L.frame = frame_dev;
+    int s = flope_yletter_launch(&L, e->dtype, stream);
+    for (size_t i = 0; i < n && !s; ++i) {
+      const Op& op = e->ops[i];
+      hipEventRecord(ev[i], st);
+      switch (op.kind) {
+        case Op::CONV: s = flope_yconv_launch(&op.conv, e->dtype, op.nt, st); break;
+        case Op::DW: s = flope_ydw_launch(&op.dw, e->dtype, st); break;
+        case Op::POOL: s = flope_ypool_launch(&op.pool, e->dtype, st); break;
+        case Op::UP: s = flope_yup_launch(&op.up, st); break;
+        case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, st); break;
+      }
+    }
+    hipEventRecord(ev[n], st);
+    if (s || hipStreamSynchronize(st) != hipSuccess) { rc = yfail(e, FLOPE_EHIP, "flope_yolo_profile: launch failed"); break; }
+    if (it == 0) continue;                           // warm-up
+    for (size_t i = 0; i < n; ++i) { float ms = 0.f; hipEventElapsedTime(&ms, ev[i], ev[i + 1]); us[i] += ms * 1e3; }
+  }
+  for (auto& x : ev) hipEventDestroy(x);
+  if (rc) return rc;
+  std::string t;
+  char line[256];
+  double total = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    const Op& op = e->ops[i];
+    const double u = us[i] / iters;
+    total += u;
+    if (op.kind == Op::CONV)
+      snprintf(line, sizeof line, "%3zu %7.2f conv%d s%d %4dx%-4d cin %4d cout %4d nt %d mode %d %s\n", i, u, op.conv.k, op.conv.stride, op.conv.Ho, op.conv.Wo,
+               op.conv.Cin, op.conv.Cout, op.nt, op.conv.out_mode, op.name.c_str());
+    else
+      snprintf(line, sizeof line, "%3zu %7.2f %s %s\n", i, u, op.kind == Op::DW ? "dw" : op.kind == Op::POOL ? "pool" : op.kind == Op::UP ? "up" : "attn", op.name.c_str());
+    t += line;
+  }
+  snprintf(line, sizeof line, "total %.1f us over %zu launches\n", total, n);
+  t += line;
+  snprintf(text_out, (size_t)cap, "%s", t.c_str());
+  return FLOPE_OK;
+}
+
 extern "C" double flope_yolo_flops(flope_yolo_handle e) { return e ? e->flops : 0.0; }
 extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->ops.size() + 6 : 0; }   // + letterbox, decode, nms, 2 mask kernels, resize

@@ -164,6 +164,14 @@ class YoloSeg:
             self._check(rc)
         return rc
 
+    def profile(self, frame, iters: int = 20) -> str:
+        """developer aid: mean microseconds of every launch of the graph, as a text table"""
+        f = self._frame(frame)
+        buf = C.create_string_buffer(1 << 16)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.flope_yolo_profile(self.handle, f.data_ptr(), int(iters), buf, len(buf), self._own_stream.cuda_stream))
+        return buf.value.decode()
+
     def flops(self) -> float:
         return float(self.lib.flope_yolo_flops(self.handle))
 

@@ -238,6 +238,9 @@ int flope_yolo_read_tensor(flope_yolo_handle h, const char* name, float* dst_dev
  *       (both measured as no gain on MI355X: the detector is a serial chain of short kernels);
  *   "generic_attn" (default 0): C2PSA attention on the generic fp32 kernel instead of the MFMA one. */
 int flope_yolo_set_option(flope_yolo_handle h, const char* name, int value);
+/* developer aid: `iters` forwards with a HIP event pair around every launch of the graph; writes a text table (mean
+ * microseconds per launch, kind, geometry, state_dict name) into text_out[cap] */
+int flope_yolo_profile(flope_yolo_handle h, const uint8_t* frame_dev, int iters, char* text_out, int cap, void* stream);
 double flope_yolo_flops(flope_yolo_handle h);      /* 2*MAC of one forward (convs + attention) */
 int flope_yolo_launches(flope_yolo_handle h);      /* kernel launches per flope_yolo_detect */
 

@@ -577,10 +577,12 @@ def test_rotation_error_vs_conditioning_of_M(state_dict, dtype):
 
 def test_float16_activations_saturate_instead_of_overflowing(state_dict):
     """a checkpoint whose residual stream outgrows the float16 range must not turn into inf -> NaN -> a garbage
-    rotation.  Scaling one BatchNorm's gamma by 3e4 pushes layer1.0 beyond 65504: the 16-bit epilogues saturate at
+    rotation.  Scaling one BatchNorm's gamma by 1.5e5 pushes layer1.0 beyond 65504 (the folded weights stay below it): the 16-bit epilogues saturate at
     +-65504 (v_pk_min_f16), every later stage stays finite, and the rotation is still a rotation."""
     sd = dict(state_dict)
-    sd["base.layer1.0.bn2.weight"] = state_dict["base.layer1.0.bn2.weight"] * 3e4
+    sd["base.layer1.0.bn2.weight"] = state_dict["base.layer1.0.bn2.weight"] * 1.5e5
+    fold = sd["base.layer1.0.bn2.weight"] / torch.sqrt(sd["base.layer1.0.bn2.running_var"] + 1e-5)
+    assert float((sd["base.layer1.0.conv2.weight"] * fold.view(-1, 1, 1, 1)).abs().max()) < 6e4       # weights representable
     torch.manual_seed(3)
     x = torch.rand(3, 3, 224, 224)
     e = _engine(sd, 224, 224, 3, "f16")

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=0, help="run only this many detects (for rocprofv3)")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--per-launch", action="store_true", help="print the per-launch time table (HIP events) and exit")
     args = ap.parse_args()
     from flope_amd.yolo import YoloSeg
     from flope_amd.yolo_weights import synthetic_frame, synthetic_yolo_state_dict
@@ -27,6 +28,9 @@ def main():
     y.set_option("graph", args.graph)
     y.set_option("streams", args.streams)
     frame = torch.from_numpy(synthetic_frame(0)).cuda()
+    if args.per_launch:
+        print(y.profile(frame, 20))
+        return
     n = args.profile_iters or args.iters
     for _ in range(3 if args.profile_iters else 10):
         y.detect_device(frame)
