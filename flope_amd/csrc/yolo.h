@@ -36,6 +36,17 @@ struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU
   int blk, blk_stride, blk_off;              // blk != 0: input channel of output channel c = (c / blk) * blk_stride + blk_off + c % blk
 };
 
+// ymulti_kernel: up to kYMultiMax independent conv / depthwise launches sharing one grid
+constexpr int kYMultiMax = 8;
+struct YMultiOp {
+  int code;                                  // 0..11: conv, (NT index 0/1/2) * 4 + (3x3 ? 2 : 0) + (split-K ? 1 : 0); 12: depthwise
+  int nbx;                                   // conv: workgroups along pixels (local block b -> (b % nbx, b / nbx))
+  int start;                                 // first workgroup of this op in the grid
+  int pad_;
+  union U { YConvP c; YDwP d; } u;
+};
+struct YMultiP { int n, total; YMultiOp op[kYMultiMax]; };
+
 struct YPoolP { const void* in; int H, W, C, ldi; void* out; int ldo; };           // 5x5 s1 p2 max-pool, -inf border
 struct YUpP { const void* in; int H, W, C, ldi; void* out; int ldo; };             // nearest 2x: out is [2H][2W]
 

@@ -31,15 +31,16 @@ template <typename T> __device__ __forceinline__ float ld16(const void* p) { ret
 // handful of workgroups and its serial K loop -- one L2 / Infinity-Cache round trip per step -- IS its latency.
 // Every variant keeps PD = 4 K steps of operand fragments in flight (the first version prefetched one step: 0.7 us per
 // step on the 23 x 40 maps, 50 us for a 72-step layer).
+// `red`: the workgroup's LDS scratch for the SPLITK combine, 3 * 2 * NT * 4 * 64 floats (24 KB at NT = 4).
 template <typename T, int NT, bool K3, bool SPLITK>
-__global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
+__device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const int by, float* const red) {
   typedef typename Elem<T>::frag frag;
   constexpr int MTW = 2, CB = 16 * NT, PD = 4;       // pixel tiles per wave, channels per block, pipeline depth
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c16 = lane & 15;
-  const int m_base = SPLITK ? blockIdx.x * (16 * MTW) : (blockIdx.x * 4 + wave) * (16 * MTW);
+  const int m_base = SPLITK ? bx * (16 * MTW) : (bx * 4 + wave) * (16 * MTW);
   if (!SPLITK && m_base >= p.M) return;
-  const int nblk = blockIdx.y;
+  const int nblk = by;
   const int pad = K3 ? 1 : 0;
   const size_t Kp2 = (size_t)p.ksteps * 64;          // bytes per weight row
   int iy0[MTW], ix0[MTW];
@@ -110,14 +111,14 @@ __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
     }
   }
   if constexpr (SPLITK) {
-    __shared__ float red[3][MTW * NT * 4][64];
+    constexpr int RW = MTW * NT * 4;
     if (wave != 0) {
 #pragma unroll
       for (int pt = 0; pt < MTW; ++pt)
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) red[wave - 1][(pt * NT + ct) * 4 + q][lane] = acc[pt][ct][q];
+          for (int q = 0; q < 4; ++q) red[((wave - 1) * RW + (pt * NT + ct) * 4 + q) * 64 + lane] = acc[pt][ct][q];
     }
     __syncthreads();
     if (wave != 0) return;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[pt][ct][q] += red[w][(pt * NT + ct) * 4 + q][lane];
+          for (int q = 0; q < 4; ++q) acc[pt][ct][q] += red[(w * RW + (pt * NT + ct) * 4 + q) * 64 + lane];
   }
   // ---- epilogue: this lane = pixel c16 of each tile x channels ch0 .. ch0 + 4 NT - 1
   const int ch0 = nblk * CB + g * 4 * NT;
@@ -189,11 +190,17 @@ __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
   }
 }
 
+template <typename T, int NT, bool K3, bool SPLITK>
+__global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
+  __shared__ float red[SPLITK ? 3 * 2 * NT * 4 * 64 : 1];
+  yconv_body<T, NT, K3, SPLITK>(p, blockIdx.x, blockIdx.y, red);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void ydw_kernel(const YDwP p) {
+__device__ __forceinline__ void ydw_body(const YDwP& p, const int bx) {
   const int c8n = p.C >> 3;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = bx * 256 + threadIdx.x;
   if (idx >= p.H * p.W * c8n) return;
   const int pix = idx / c8n, c0 = (idx - pix * c8n) * 8;
   const int y = pix / p.W, x = pix - y * p.W;
@@ -225,6 +232,39 @@ __global__ __launch_bounds__(256) void ydw_kernel(const YDwP p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) o[q] = pk_out16<T>(pack2<T>(a[2 * q], a[2 * q + 1]), false);
   *(u32x4*)((char*)p.out + ((size_t)pix * p.ldo + c0) * 2) = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ydw_kernel(const YDwP p) { ydw_body<T>(p, blockIdx.x); }
+
+// Several INDEPENDENT launches of the graph in one grid (the Segment head's box / class / coefficient branches, the Proto
+// block beside them, the two 1x1 convs of a C3k that read the same map ...): every one of them is a few dozen workgroups with
+// a serial K loop, far too small to fill 256 CUs, and each costs a whole dependent launch when queued alone.  Workgroup b
+// belongs to op s with start[s] <= b < start[s+1]; the op's parameters are read from the kernel arguments (uniform).
+template <typename T>
+__global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP P) {
+  __shared__ float red[3 * 2 * 4 * 4 * 64];
+  const int b = blockIdx.x;
+  int s = 0;
+  for (int i = 1; i < P.n; ++i) s = b >= P.op[i].start ? i : s;
+  const YMultiOp& o = P.op[s];
+  const int lb = b - o.start;
+  if (o.code == 12) { ydw_body<T>(o.u.d, lb); return; }
+  const int by = lb / o.nbx, bx = lb - by * o.nbx;
+  switch (o.code) {
+    case 0: yconv_body<T, 1, false, false>(o.u.c, bx, by, red); break;
+    case 1: yconv_body<T, 1, false, true>(o.u.c, bx, by, red); break;
+    case 2: yconv_body<T, 1, true, false>(o.u.c, bx, by, red); break;
+    case 3: yconv_body<T, 1, true, true>(o.u.c, bx, by, red); break;
+    case 4: yconv_body<T, 2, false, false>(o.u.c, bx, by, red); break;
+    case 5: yconv_body<T, 2, false, true>(o.u.c, bx, by, red); break;
+    case 6: yconv_body<T, 2, true, false>(o.u.c, bx, by, red); break;
+    case 7: yconv_body<T, 2, true, true>(o.u.c, bx, by, red); break;
+    case 8: yconv_body<T, 4, false, false>(o.u.c, bx, by, red); break;
+    case 9: yconv_body<T, 4, false, true>(o.u.c, bx, by, red); break;
+    case 10: yconv_body<T, 4, true, false>(o.u.c, bx, by, red); break;
+    default: yconv_body<T, 4, true, true>(o.u.c, bx, by, red); break;
+  }
 }
 
 template <typename T>
@@ -733,14 +773,47 @@ static void yconv_go(const YConvP& p, int nt, bool splitk, dim3 grid, hipStream_
 #undef GO
 }
 
+static bool yconv_geometry(const YConvP* p, int nt, bool* splitk, int* nbx, int* nby) {
+  if ((p->k != 1 && p->k != 3) || p->Cin % 8 || (nt != 1 && nt != 2 && nt != 4) || p->M < 1) return false;
+  const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
+  if (p->out_mode == 2 && (p->dc % (16 * nt) || p->res)) return false;
+  *splitk = p->M <= 16384 && p->ksteps >= 8;                 // small map, long K: one tile per workgroup, K over its 4 waves
+  *nbx = *splitk ? (p->M + 31) / 32 : (p->M + 127) / 128;
+  *nby = (rows + 16 * nt - 1) / (16 * nt);
+  return true;
+}
+
 // nt = channel tiles of 16 per workgroup column (1, 2 or 4): rows of p->w / p->bias = ceil(Cout / (16 nt)) * 16 nt
 extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stream) {
-  if ((p->k != 1 && p->k != 3) || p->Cin % 8 || (nt != 1 && nt != 2 && nt != 4) || p->M < 1) return (int)hipErrorInvalidValue;
-  const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
-  if (p->out_mode == 2 && (p->dc % (16 * nt) || p->res)) return (int)hipErrorInvalidValue;
-  const bool splitk = p->M <= 16384 && p->ksteps >= 8;       // small map, long K: one tile per workgroup, K over its 4 waves
-  const dim3 grid(splitk ? (p->M + 31) / 32 : (p->M + 127) / 128, (rows + 16 * nt - 1) / (16 * nt));
+  bool splitk; int nbx, nby;
+  if (!yconv_geometry(p, nt, &splitk, &nbx, &nby)) return (int)hipErrorInvalidValue;
+  const dim3 grid(nbx, nby);
   if (dtype == 0) yconv_go<bf16_t>(*p, nt, splitk, grid, (hipStream_t)stream); else yconv_go<f16_t>(*p, nt, splitk, grid, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+// ---- several independent ops in one grid (ymulti_kernel) ---------------------------------------------------------
+extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt) {
+  bool splitk; int nbx, nby;
+  if (m->n >= kYMultiMax || !yconv_geometry(p, nt, &splitk, &nbx, &nby)) return (int)hipErrorInvalidValue;
+  YMultiOp& o = m->op[m->n++];
+  o.code = (nt == 1 ? 0 : nt == 2 ? 4 : 8) + (p->k == 3 ? 2 : 0) + (splitk ? 1 : 0);
+  o.nbx = nbx; o.start = m->total; o.u.c = *p;
+  m->total += nbx * nby;
+  return 0;
+}
+
+extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p) {
+  if (m->n >= kYMultiMax || p->C % 8) return (int)hipErrorInvalidValue;
+  YMultiOp& o = m->op[m->n++];
+  o.code = 12; o.nbx = 1; o.start = m->total; o.u.d = *p;
+  m->total += (p->H * p->W * (p->C / 8) + 255) / 256;
+  return 0;
+}
+
+extern "C" int flope_ymulti_launch(const YMultiP* m, int dtype, void* stream) {
+  if (m->n < 1 || m->n > kYMultiMax || m->total < 1) return (int)hipErrorInvalidValue;
+  YDISPATCH(dtype, ymulti_kernel, dim3(m->total), dim3(256), 0, (hipStream_t)stream, *m);
   return (int)hipGetLastError();
 }
 

@@ -23,6 +23,9 @@
 
 extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stream);
 extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream);
+extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt);
+extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p);
+extern "C" int flope_ymulti_launch(const YMultiP* m, int dtype, void* stream);
 extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream);
 extern "C" int flope_yup_launch(const YUpP* p, void* stream);
 extern "C" int flope_yattn_init();
@@ -41,25 +44,27 @@ namespace {
 thread_local std::string g_yolo_error;
 constexpr double kYoloBnEps = 1e-3;            // ultralytics: BatchNorm2d(eps=0.001)
 constexpr int kRegMax = 16, kNm = 32, kMaxDet = 300;
-constexpr int kSide = 4;                       // side streams: proto, box, class and coefficient branches of the Segment head
-constexpr int kEvents = 3 + kSide;             // features of the three levels ready; one join event per side stream
 
 struct View { int t = -1, off = 0, C = 0; };   // channel slice [off, off + C) of tensor t
 struct Tensor { void* ptr = nullptr; int H = 0, W = 0, C = 0; };
+struct Rng { int t, c0, c1; };                 // what an op touches: channels [c0, c1) of tensor t (t < 0: prediction-row columns)
 
 struct Op {
   enum Kind { CONV, DW, POOL, UP, ATTN } kind;
   int nt = 4;
-  int stream = 0;                 // 0 = the caller's stream; 1..kSide = internal side streams (independent head branches)
-  int wait_ev = -1, rec_ev = -1;  // event to wait for before / to record after this launch
+  int level = 0;                  // longest dependency chain before this op (ops of one level are independent)
   YConvP conv; YDwP dw; YPoolP pool; YUpP up; YAttnP attn;
+  std::vector<Rng> reads, writes;
   std::string name;
 };
+
+// One launch of the schedule: a single op, or up to kYMultiMax independent conv / depthwise ops of one level in one grid.
+struct Launch { int op = -1; YMultiP multi; std::vector<int> members; };
 
 struct Tap { int is_f32 = 0; const void* ptr = nullptr; int H = 0, W = 0, C = 0, ld = 0; };
 
 struct GraphKey {                 // what a captured detect sequence bakes in
-  const void* frame; void* det; void* count; void* mask; float conf, iou; int max_det, streams, generic_attn;
+  const void* frame; void* det; void* count; void* mask; float conf, iou; int max_det, batch, generic_attn;
 };
 
 }  // namespace
@@ -71,22 +76,22 @@ struct flope_yolo {
   int nc = 0, no = 0, A = 0;
   std::vector<Tensor> tensors;
   std::vector<void*> owned;                                   // weights, biases, scratch
-  std::vector<Op> ops;
+  std::vector<Op> ops;                                        // program order of the ultralytics graph
+  std::vector<Launch> sched[2];                               // [0]: one launch per op in program order; [1]: levels, batched
   std::map<std::string, Tap> taps;
   void* zero = nullptr;
   float* pred = nullptr;
   YLetterP letter; YDecodeP dec; YNmsP nms; YMaskP mask;
   uint8_t* merged = nullptr;
   int opt_generic_attn = 0;                                   // A/B + parity of the two attention kernels
-  // Both measured as no gain on MI355X (r02, 1080p / imgsz 1280, yolo11n-seg): the detector is bound by the serial chain of
-  // ~115 short kernels on the GPU, not by host launches (hipGraph replay 1.196 vs eager 1.188 ms), and every cross-stream
-  // dependency costs more than the overlap returns (side streams 1.31 ms eager, 1.45 ms in a graph).  Kept as options.
-  int opt_streams = 0;                                        // 1: head branches on side streams; 0 (default): one stream
+  // The detector is a chain of ~100 launches of 5-12 us each on one frame: the GPU, not the host, is the bound (hipGraph
+  // replay 1.196 vs eager 1.188 ms, r02), and independent branches on side streams cost more in cross-stream dependencies
+  // than the overlap returned (1.31 ms; removed).  What does pay is putting the independent ops of one dependency level
+  // into ONE grid (ymulti_kernel): option "batch", default on.
+  int opt_batch = 1;
   int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
   hipGraphExec_t graph_exec = nullptr;
   GraphKey graph_key = {};
-  hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev[kEvents] = {};
   double flops = 0.0;
   std::string err;
 };
@@ -109,13 +114,9 @@ struct Builder {
   flope_yolo* e;
   std::map<std::string, std::pair<const float*, std::vector<int64_t>>> sd;
   int rc = 0;
-  int cur_stream = 0, pending_wait = -1;      // stream of the ops emitted next; event the next op has to wait for
-  void push(Op& op) {
-    op.stream = cur_stream; op.wait_ev = pending_wait; pending_wait = -1;
-    e->ops.push_back(op);
-  }
-  void on_stream(int s, int wait_ev) { cur_stream = s; pending_wait = wait_ev; }
-  void record_after_last(int ev) { if (!e->ops.empty()) e->ops.back().rec_ev = ev; }
+  int n_pred = 0;                             // prediction-row column blocks written so far (each its own pseudo tensor)
+  void push(Op& op) { e->ops.push_back(op); }
+  static Rng rng(const View& v) { return Rng{v.t, v.off, v.off + v.C}; }
 
   bool has(const std::string& k) const { return sd.count(k) != 0; }
   const std::vector<int64_t>* shape(const std::string& k) {
@@ -235,6 +236,9 @@ struct Builder {
     fastdiv_magic((unsigned)c.cg, &c.cg_mg, &c.cg_sh);
     c.out_mode = out_mode; c.dc = out_mode == 2 ? co / 4 : 0;
     e->flops += 2.0 * c.M * (double)rows * cin * k * k;
+    op.reads.push_back(rng(in));
+    if (res) op.reads.push_back(rng(*res));
+    if (out_mode == 1) op.writes.push_back(Rng{-(++n_pred), 0, 1}); else op.writes.push_back(rng(out));
     push(op);
   }
 
@@ -292,6 +296,9 @@ struct Builder {
     d.w = (const float*)upload(wf); d.bias = (const float*)upload(bf); d.act = act;
     d.blk = blk; d.blk_stride = blk_stride; d.blk_off = blk_off;
     e->flops += 2.0 * d.H * d.W * (double)c * 9;
+    op.reads.push_back(rng(in));
+    if (add) op.reads.push_back(rng(*add));
+    op.writes.push_back(rng(out));
     push(op);
   }
 
@@ -299,12 +306,14 @@ struct Builder {
     Op op; op.kind = Op::POOL; op.name = "maxpool5";
     op.pool.in = vptr(in); op.pool.H = vH(in); op.pool.W = vW(in); op.pool.C = in.C; op.pool.ldi = vld(in);
     op.pool.out = vptr(out); op.pool.ldo = vld(out);
+    op.reads.push_back(rng(in)); op.writes.push_back(rng(out));
     push(op);
   }
   void upsample(const View& in, const View& out) {
     Op op; op.kind = Op::UP; op.name = "upsample2x";
     op.up.in = vptr(in); op.up.H = vH(in); op.up.W = vW(in); op.up.C = in.C; op.up.ldi = vld(in);
     op.up.out = vptr(out); op.up.ldo = vld(out);
+    op.reads.push_back(rng(in)); op.writes.push_back(rng(out));
     push(op);
   }
 
@@ -364,6 +373,7 @@ struct Builder {
       op.attn.qkv = vptr(full(qkv)); op.attn.N = H * W; op.attn.heads = heads; op.attn.ld = heads * 128;
       op.attn.out = vptr(full(att)); op.attn.ldo = c; op.attn.scale = 1.0f / sqrtf(32.f);
       e->flops += 2.0 * heads * (double)H * W * H * W * (32 + 64);
+      op.reads.push_back(rng(full(qkv))); op.writes.push_back(rng(full(att)));
       push(op);
       const View va = full(att);
       dw(q + ".attn.pe", full(qkv), full(att2), 0, &va, 64, 128, 64);            // (v @ attn^T) + pe(v)
@@ -375,33 +385,78 @@ struct Builder {
   }
 };
 
-int run_ops(flope_yolo* e, void* stream) {
-  hipStream_t user = (hipStream_t)stream;
-  const bool multi = e->opt_streams != 0;
-  bool used[kSide] = {false, false, false, false};
-  for (const Op& op : e->ops) {
-    hipStream_t st = (multi && op.stream > 0) ? e->side[op.stream - 1] : user;
-    if (multi && op.stream > 0) used[op.stream - 1] = true;
-    if (multi && op.wait_ev >= 0 && hipStreamWaitEvent(st, e->ev[op.wait_ev], 0) != hipSuccess) return yfail(e, FLOPE_EHIP, "hipStreamWaitEvent failed");
-    int s = 0;
-    switch (op.kind) {
-      case Op::CONV: s = flope_yconv_launch(&op.conv, e->dtype, op.nt, st); break;
-      case Op::DW: s = flope_ydw_launch(&op.dw, e->dtype, st); break;
-      case Op::POOL: s = flope_ypool_launch(&op.pool, e->dtype, st); break;
-      case Op::UP: s = flope_yup_launch(&op.up, st); break;
-      case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, st); break;
-    }
-    if (s != 0) {
-      for (int i = 0; i < kSide; ++i) if (used[i]) hipStreamSynchronize(e->side[i]);      // leave nothing unordered behind
-      return yfail(e, FLOPE_EHIP, op.name + ": " + hipGetErrorString((hipError_t)s));
-    }
-    if (multi && op.rec_ev >= 0 && hipEventRecord(e->ev[op.rec_ev], st) != hipSuccess) return yfail(e, FLOPE_EHIP, "hipEventRecord failed");
+int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
+  switch (op.kind) {
+    case Op::CONV: return flope_yconv_launch(&op.conv, e->dtype, op.nt, st);
+    case Op::DW: return flope_ydw_launch(&op.dw, e->dtype, st);
+    case Op::POOL: return flope_ypool_launch(&op.pool, e->dtype, st);
+    case Op::UP: return flope_yup_launch(&op.up, st);
+    case Op::ATTN: return flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, st);
   }
-  for (int i = 0; i < kSide; ++i)           // join: the caller's stream continues only after every branch
-    if (used[i] && (hipEventRecord(e->ev[3 + i], e->side[i]) != hipSuccess || hipStreamWaitEvent(user, e->ev[3 + i], 0) != hipSuccess)) {
-      hipStreamSynchronize(e->side[i]);
-      return yfail(e, FLOPE_EHIP, "joining the head-branch streams failed");
+  return (int)hipErrorInvalidValue;
+}
+
+int launch_one(flope_yolo* e, const Launch& L, hipStream_t st) {
+  return L.op >= 0 ? launch_op(e, e->ops[L.op], st) : flope_ymulti_launch(&L.multi, e->dtype, st);
+}
+
+std::string launch_name(const flope_yolo* e, const Launch& L) {
+  if (L.op >= 0) return e->ops[L.op].name;
+  std::string n;
+  for (int i : L.members) n += (n.empty() ? "" : " | ") + e->ops[i].name;
+  return n;
+}
+
+int run_ops(flope_yolo* e, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  for (const Launch& L : e->sched[e->opt_batch ? 1 : 0]) {
+    const int s = launch_one(e, L, st);
+    if (s != 0) return yfail(e, FLOPE_EHIP, launch_name(e, L) + ": " + hipGetErrorString((hipError_t)s));
+  }
+  return FLOPE_OK;
+}
+
+// Dependency levels from the read / write sets (RAW, WAW, WAR on overlapping channel ranges of one tensor), then the two
+// schedules: program order, and level order with the conv / depthwise ops of a level sharing grids of <= kYMultiMax ops.
+int build_schedules(flope_yolo* e) {
+  auto hit = [](const std::vector<Rng>& a, const std::vector<Rng>& b) {
+    for (const Rng& x : a)
+      for (const Rng& y : b)
+        if (x.t == y.t && x.c0 < y.c1 && y.c0 < x.c1) return true;
+    return false;
+  };
+  const int n = (int)e->ops.size();
+  int depth = 0;
+  for (int i = 0; i < n; ++i) {
+    Op& oi = e->ops[i];
+    oi.level = 0;
+    for (int j = 0; j < i; ++j) {
+      const Op& oj = e->ops[j];
+      if (hit(oj.writes, oi.reads) || hit(oj.writes, oi.writes) || hit(oj.reads, oi.writes)) oi.level = std::max(oi.level, oj.level + 1);
     }
+    depth = std::max(depth, oi.level + 1);
+  }
+  e->sched[0].clear(); e->sched[1].clear();
+  for (int i = 0; i < n; ++i) { Launch L; L.op = i; e->sched[0].push_back(L); }
+  for (int lv = 0; lv < depth; ++lv) {
+    std::vector<int> batchable, single;
+    for (int i = 0; i < n; ++i)
+      if (e->ops[i].level == lv) ((e->ops[i].kind == Op::CONV || e->ops[i].kind == Op::DW) ? batchable : single).push_back(i);
+    for (int i : single) { Launch L; L.op = i; e->sched[1].push_back(L); }
+    for (size_t at = 0; at < batchable.size(); at += kYMultiMax) {
+      const size_t m = std::min(batchable.size() - at, (size_t)kYMultiMax);
+      Launch L;
+      if (m == 1) { L.op = batchable[at]; e->sched[1].push_back(L); continue; }
+      memset(&L.multi, 0, sizeof L.multi);
+      for (size_t k = 0; k < m; ++k) {
+        const Op& op = e->ops[batchable[at + k]];
+        const int s = op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt) : flope_ymulti_add_dw(&L.multi, &op.dw);
+        if (s) return yfail(e, FLOPE_EINVAL, "schedule: cannot batch " + op.name);
+        L.members.push_back(batchable[at + k]);
+      }
+      e->sched[1].push_back(L);
+    }
+  }
   return FLOPE_OK;
 }
 
@@ -430,10 +485,6 @@ extern "C" int flope_yolo_create(int device_id, int frame_h, int frame_w, int im
   e->h = e->nh + e->top + (int)nearbyint(dh + 0.1); e->w = e->nw + e->left + (int)nearbyint(dw + 0.1);
   if (e->h % 32 || e->w % 32) { delete e; return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: letterboxed size is not a multiple of 32"); }
   if (hipSetDevice(device_id) != hipSuccess || flope_yattn_init() != 0) { delete e; return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: device setup failed"); }
-  for (int i = 0; i < kSide; ++i)
-    if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) { flope_yolo_destroy(e); return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: hipStreamCreate failed"); }
-  for (int i = 0; i < kEvents; ++i)
-    if (hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) { flope_yolo_destroy(e); return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: hipEventCreate failed"); }
   *out = e;
   return FLOPE_OK;
 }
@@ -445,8 +496,6 @@ extern "C" int flope_yolo_destroy(flope_yolo_handle e) {
   if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
   for (Tensor& t : e->tensors) if (t.ptr) hipFree(t.ptr);
   for (void* p : e->owned) if (p) hipFree(p);
-  for (int i = 0; i < kSide; ++i) if (e->side[i]) hipStreamDestroy(e->side[i]);
-  for (int i = 0; i < kEvents; ++i) if (e->ev[i]) hipEventDestroy(e->ev[i]);
   delete e;
   return FLOPE_OK;
 }
@@ -515,34 +564,29 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
   b.upsample(o10, b.slice(cat12, 0, c10));
   b.c3k2("model.13", b.full(cat12), o13);
   b.upsample(o13, b.slice(cat15, 0, c13));
-  // The Segment head's branches only depend on their level's feature map: they go to side streams (proto, box, class,
-  // coefficients) right after that map is produced, and run beside the rest of the neck and beside each other --
-  // 40-odd launches of a few microseconds each that would otherwise queue up behind one another.
+  // The Segment head's branches (box, class, coefficients per level, Proto) only depend on their level's feature map:
+  // build_schedules() finds that from the read / write sets and lets them share grids with each other and with the neck.
   const char* nm3[3] = {"box", "cls", "coef"};
   int a0 = 0;
-  auto head_level = [&](int i, const View f, int ev_ready) {
+  auto head_level = [&](int i, const View f) {
     const int H = b.vH(f), W = b.vW(f);
     const std::string si = std::to_string(i);
     const int cb = b.cout(hd + ".cv2." + si + ".0"), cc = b.cout(hd + ".cv3." + si + ".0.1"), cm = b.cout(hd + ".cv4." + si + ".0");
     if (b.rc) return;
-    b.on_stream(2, ev_ready);
     const int b1 = b.tensor(H, W, cb), b2 = b.tensor(H, W, cb);
     b.conv(hd + ".cv2." + si + ".0", f, b.full(b1), 1, 1);
     b.conv(hd + ".cv2." + si + ".1", b.full(b1), b.full(b2), 1, 1);
     b.plain(hd + ".cv2." + si + ".2", b.full(b2), a0, 0);
-    b.on_stream(3, ev_ready);
     const int d1 = b.tensor(H, W, f.C), e1 = b.tensor(H, W, cc), d2 = b.tensor(H, W, cc), e2 = b.tensor(H, W, cc);
     b.dw(hd + ".cv3." + si + ".0.0", f, b.full(d1), 1);
     b.conv(hd + ".cv3." + si + ".0.1", b.full(d1), b.full(e1), 1, 1);
     b.dw(hd + ".cv3." + si + ".1.0", b.full(e1), b.full(d2), 1);
     b.conv(hd + ".cv3." + si + ".1.1", b.full(d2), b.full(e2), 1, 1);
     b.plain(hd + ".cv3." + si + ".2", b.full(e2), a0, 4 * kRegMax);
-    b.on_stream(4, ev_ready);
     const int m1 = b.tensor(H, W, cm), m2 = b.tensor(H, W, cm);
     b.conv(hd + ".cv4." + si + ".0", f, b.full(m1), 1, 1);
     b.conv(hd + ".cv4." + si + ".1", b.full(m1), b.full(m2), 1, 1);
     b.plain(hd + ".cv4." + si + ".2", b.full(m2), a0, 4 * kRegMax + e->nc);
-    b.on_stream(0, -1);
     const int col[3] = {0, 4 * kRegMax, 4 * kRegMax + e->nc}, cw[3] = {4 * kRegMax, e->nc, kNm};
     for (int k = 0; k < 3; ++k) {
       Tap t; t.is_f32 = 1; t.ptr = e->pred + (size_t)a0 * e->no + col[k]; t.H = H; t.W = W; t.C = cw[k]; t.ld = e->no;
@@ -552,25 +596,20 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
     a0 += H * W;
   };
   b.c3k2("model.16", b.full(cat15), b.full(t16));
-  b.record_after_last(0);
   const int npr = b.cout(hd + ".proto.cv1");
   if (b.rc) return b.rc;
   const int p1 = b.tensor(H8, W8, npr), pu = b.tensor(2 * H8, 2 * W8, npr), p2 = b.tensor(2 * H8, 2 * W8, npr), pr = b.tensor(2 * H8, 2 * W8, kNm);
-  b.on_stream(1, 0);
   b.conv(hd + ".proto.cv1", b.full(t16), b.full(p1), 1, 1);
   b.deconv(hd + ".proto.upsample", b.full(p1), b.full(pu));
   b.conv(hd + ".proto.cv2", b.full(pu), b.full(p2), 1, 1);
   b.conv(hd + ".proto.cv3", b.full(p2), b.full(pr), 1, 1);
-  b.on_stream(0, -1);
-  head_level(0, b.full(t16), 0);
+  head_level(0, b.full(t16));
   b.conv("model.17", b.full(t16), b.slice(cat18, 0, c17), 2, 1);
   b.c3k2("model.19", b.full(cat18), b.full(t19));
-  b.record_after_last(1);
-  head_level(1, b.full(t19), 1);
+  head_level(1, b.full(t19));
   b.conv("model.20", b.full(t19), b.slice(cat21, 0, c20), 2, 1);
   b.c3k2("model.22", b.full(cat21), b.full(t22));
-  b.record_after_last(2);
-  head_level(2, b.full(t22), 2);
+  head_level(2, b.full(t22));
   e->dec.lvl_a0[3] = a0;
   if (b.rc) return b.rc;
   b.tap("input", b.full(x));
@@ -620,6 +659,7 @@ extern "C" int flope_yolo_load_weights(flope_yolo_handle e, int n, const char* c
   L.H = e->H; L.W = e->W; L.out = e->tensors[x].ptr; L.h = h; L.w = w; L.nh = e->nh; L.nw = e->nw; L.top = e->top; L.left = e->left;
   L.sx = 1.0 / ((double)e->nw / e->W); L.sy = 1.0 / ((double)e->nh / e->H);
   if (b.rc) return b.rc;
+  if (int rc = build_schedules(e)) return rc;
   Y_TRY(e, hipDeviceSynchronize());
   e->loaded = true;
   return FLOPE_OK;
@@ -652,8 +692,7 @@ static int detect_body(flope_yolo* e, const uint8_t* frame_dev, float conf, floa
 }
 
 // "graph" option: the launch sequence of one (frame buffer, thresholds, output buffers) tuple is captured once into a
-// hipGraph (with "streams": head branches as parallel graph branches) and replayed afterwards.  Frees the host; does not
-// shorten the frame on MI355X (see the option defaults above).
+// hipGraph and replayed afterwards.  Frees the host; does not shorten the frame on MI355X (see the option defaults above).
 extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, float conf, float iou, int max_det,
                                  float* det_dev, int32_t* count_dev, uint8_t* mask_dev, void* stream) {
   if (!e) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_detect: NULL handle");
@@ -664,7 +703,7 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   if (!e->opt_graph) return detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_streams, e->opt_generic_attn};
+  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch, e->opt_generic_attn};
   if (!e->graph_exec || memcmp(&key, &e->graph_key, sizeof key) != 0) {
     if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
     hipGraph_t g = nullptr;
@@ -702,7 +741,7 @@ extern "C" int flope_yolo_read_tensor(flope_yolo_handle e, const char* name, flo
 extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int value) {
   if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
-  if (!strcmp(name, "streams")) { const int prev = e->opt_streams; e->opt_streams = value != 0; return prev; }
+  if (!strcmp(name, "batch")) { const int prev = e->opt_batch; e->opt_batch = value != 0; return prev; }
   if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
 }
@@ -714,7 +753,8 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
   if (!e->loaded) return yfail(e, FLOPE_ESTATE, "flope_yolo_profile before flope_yolo_load_weights");
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  const size_t n = e->ops.size();
+  const std::vector<Launch>& sched = e->sched[e->opt_batch ? 1 : 0];
+  const size_t n = sched.size();
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& x : ev) Y_TRY(e, hipEventCreate(&x));
   std::vector<double> us(n, 0.0);
@@ -723,15 +763,8 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
     YLetterP L = e->letter; L.frame = frame_dev;
     int s = flope_yletter_launch(&L, e->dtype, stream);
     for (size_t i = 0; i < n && !s; ++i) {
-      const Op& op = e->ops[i];
       hipEventRecord(ev[i], st);
-      switch (op.kind) {
-        case Op::CONV: s = flope_yconv_launch(&op.conv, e->dtype, op.nt, st); break;
-        case Op::DW: s = flope_ydw_launch(&op.dw, e->dtype, st); break;
-        case Op::POOL: s = flope_ypool_launch(&op.pool, e->dtype, st); break;
-        case Op::UP: s = flope_yup_launch(&op.up, st); break;
-        case Op::ATTN: s = flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, st); break;
-      }
+      s = launch_one(e, sched[i], st);
     }
     hipEventRecord(ev[n], st);
     if (s || hipStreamSynchronize(st) != hipSuccess) { rc = yfail(e, FLOPE_EHIP, "flope_yolo_profile: launch failed"); break; }
@@ -741,24 +774,29 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
   for (auto& x : ev) hipEventDestroy(x);
   if (rc) return rc;
   std::string t;
-  char line[256];
+  char line[320];
   double total = 0.0;
   for (size_t i = 0; i < n; ++i) {
-    const Op& op = e->ops[i];
     const double u = us[i] / iters;
     total += u;
-    if (op.kind == Op::CONV)
-      snprintf(line, sizeof line, "%3zu %7.2f conv%d s%d %4dx%-4d cin %4d cout %4d nt %d mode %d %s\n", i, u, op.conv.k, op.conv.stride, op.conv.Ho, op.conv.Wo,
-               op.conv.Cin, op.conv.Cout, op.nt, op.conv.out_mode, op.name.c_str());
-    else
-      snprintf(line, sizeof line, "%3zu %7.2f %s %s\n", i, u, op.kind == Op::DW ? "dw" : op.kind == Op::POOL ? "pool" : op.kind == Op::UP ? "up" : "attn", op.name.c_str());
+    if (sched[i].op >= 0 && e->ops[sched[i].op].kind == Op::CONV) {
+      const Op& op = e->ops[sched[i].op];
+      snprintf(line, sizeof line, "%3zu %7.2f L%-2d conv%d s%d %4dx%-4d cin %4d cout %4d nt %d mode %d %s\n", i, u, op.level, op.conv.k, op.conv.stride, op.conv.Ho,
+               op.conv.Wo, op.conv.Cin, op.conv.Cout, op.nt, op.conv.out_mode, op.name.c_str());
+    } else if (sched[i].op >= 0) {
+      const Op& op = e->ops[sched[i].op];
+      snprintf(line, sizeof line, "%3zu %7.2f L%-2d %s %s\n", i, u, op.level, op.kind == Op::DW ? "dw" : op.kind == Op::POOL ? "pool" : op.kind == Op::UP ? "up" : "attn", op.name.c_str());
+    } else {
+      snprintf(line, sizeof line, "%3zu %7.2f L%-2d multi x%d (%d workgroups) %.200s\n", i, u, e->ops[sched[i].members[0]].level, sched[i].multi.n, sched[i].multi.total,
+               launch_name(e, sched[i]).c_str());
+    }
     t += line;
   }
-  snprintf(line, sizeof line, "total %.1f us over %zu launches\n", total, n);
+  snprintf(line, sizeof line, "total %.1f us over %zu launches (%zu ops)\n", total, n, e->ops.size());
   t += line;
   snprintf(text_out, (size_t)cap, "%s", t.c_str());
   return FLOPE_OK;
 }
 
 extern "C" double flope_yolo_flops(flope_yolo_handle e) { return e ? e->flops : 0.0; }
-extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->ops.size() + 6 : 0; }   // + letterbox, decode, nms, 2 mask kernels, resize
+extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->sched[e->opt_batch ? 1 : 0].size() + 6 : 0; }   // + letterbox, decode, nms, 2 mask kernels, resize

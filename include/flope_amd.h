@@ -233,9 +233,11 @@ int flope_yolo_forward(flope_yolo_handle h, const uint8_t* frame_dev, void* stre
 int flope_yolo_read_tensor(flope_yolo_handle h, const char* name, float* dst_dev, int64_t* dims_out, void* stream);
 /* runtime knobs (A/B variants inside one build; each returns the previous value or <0):
  *   "graph" (default 0): flope_yolo_detect captures its launch sequence into a hipGraph the first time it sees a
- *       (frame_dev, thresholds, output buffers) tuple and replays it afterwards -- keep those pointers stable across frames;
- *   "streams" (default 0): the Segment head's branches run on internal side streams / as parallel graph branches
- *       (both measured as no gain on MI355X: the detector is a serial chain of short kernels);
+ *       (frame_dev, thresholds, output buffers) tuple and replays it afterwards -- keep those pointers stable across frames
+ *       (measured as no gain on MI355X: the GPU-side chain of short kernels is the bound, not the host);
+ *   "batch" (default 1): the independent launches of one dependency level of the graph (the Segment head's box / class /
+ *       coefficient branches of a level, the Proto block beside them, parallel 1x1 convs inside C3k) share one grid; 0: one
+ *       launch per op in the program order of the ultralytics yaml;
  *   "generic_attn" (default 0): C2PSA attention on the generic fp32 kernel instead of the MFMA one. */
 int flope_yolo_set_option(flope_yolo_handle h, const char* name, int value);
 /* developer aid: `iters` forwards with a HIP event pair around every launch of the graph; writes a text table (mean

@@ -71,23 +71,27 @@ def test_attention_kernels_agree(ysd):
     y.close()
 
 
-def test_head_branch_streams_do_not_change_a_bit(ysd):
-    """The Segment head's branches run on four internal side streams / as parallel branches of the captured hipGraph;
-    one stream, eager launches give the identical result."""
+def test_batched_launches_and_graph_replay_do_not_change_a_bit(ysd):
+    """Default schedule: the independent ops of one dependency level (Segment-head branches, Proto, the parallel 1x1 convs
+    of C3k ...) share one grid (ymulti_kernel).  One launch per op in program order, and a captured hipGraph replay of
+    either, give the identical result: every graph output, the head rows, boxes and the mask."""
     from flope_amd.yolo_weights import synthetic_frame
     img = synthetic_frame(9, 1080, 1920)
     y = _engine(ysd, 1080, 1920, 1280)
-    outs = []
-    for streams, graph in ((1, 1), (0, 0), (1, 0), (0, 1), (1, 1)):      # captured hipGraph replay and eager launches
-        y.set_option("streams", streams)
+    outs, launches = [], []
+    for batch, graph in ((1, 1), (0, 0), (1, 0), (0, 1), (1, 1)):        # captured hipGraph replay and eager launches
+        y.set_option("batch", batch)
         y.set_option("graph", graph)
         boxes, sc, cls, anchor, mask = y.detect(img, 0.1)
         boxes, sc, cls, anchor, mask = y.detect(img, 0.1)                 # second call: replay of the captured graph
-        outs.append((boxes, sc, anchor, mask, y.read_tensor("proto").cpu().numpy(), y.read_tensor("cls2").cpu().numpy()))
+        outs.append([boxes, sc, anchor, mask] + [y.read_tensor(k).cpu().numpy() for k in
+                                                 ("proto", "cls2", "box0", "coef1", "4", "10", "13", "16", "19", "22")])
+        launches.append(y.launches())
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert np.array_equal(a, b)
     assert len(outs[0][2]) >= 10
+    assert launches[0] == launches[2] and launches[1] == launches[3] and launches[0] < launches[1] - 20, launches
     y.close()
 
 

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--profile-iters", type=int, default=0, help="run only this many detects (for rocprofv3)")
     ap.add_argument("--graph", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=1, help="0: one launch per op in program order")
     ap.add_argument("--per-launch", action="store_true", help="print the per-launch time table (HIP events) and exit")
     args = ap.parse_args()
     from flope_amd.yolo import YoloSeg
@@ -26,7 +26,7 @@ def main():
     y = YoloSeg(1080, 1920, 1280, args.dtype)
     y.load_state_dict(synthetic_yolo_state_dict(0))
     y.set_option("graph", args.graph)
-    y.set_option("streams", args.streams)
+    y.set_option("batch", args.batch)
     frame = torch.from_numpy(synthetic_frame(0)).cuda()
     if args.per_launch:
         print(y.profile(frame, 20))
@@ -42,7 +42,7 @@ def main():
     dt = (time.perf_counter() - t0) / n
     print(json.dumps({"detector_ms_per_frame": round(dt * 1e3, 4), "frames_per_s": round(1 / dt, 1), "detections": int(count.item()),
                       "launches": y.launches(), "gflop_per_frame": round(y.flops() / 1e9, 2),
-                      "tflops": round(y.flops() / dt / 1e12, 2), "input": list(y.input_hw), "dtype": args.dtype, "graph": args.graph, "streams": args.streams}))
+                      "tflops": round(y.flops() / dt / 1e12, 2), "input": list(y.input_hw), "dtype": args.dtype, "graph": args.graph, "batch": args.batch}))
 
 
 if __name__ == "__main__":
