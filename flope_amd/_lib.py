@@ -42,6 +42,8 @@ SIGNATURES = {
     "flope_launch_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_D)]),
     "flope_describe_plan": (_I, [_P, C.c_char_p, _I]),
     "flope_version": (C.c_char_p, []),
+    "flope_stream_create_cu_mask": (_I, [_I, C.POINTER(C.c_uint32), _I, C.POINTER(_P)]),
+    "flope_stream_destroy": (_I, [_I, _P]),
     "flope_yolo_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_P)]),
     "flope_yolo_destroy": (_I, [_P]),
     "flope_yolo_last_error": (C.c_char_p, [_P]),

@@ -304,6 +304,28 @@ int fold(flope_engine* e, const Tensors& ts, const std::string& conv, const std:
 }  // namespace
 
 // ================================================================================
+// A HIP stream whose kernels may only occupy the compute units set in `mask` (bit i of word i / 32 = CU i in the runtime's
+// enumeration, which walks the XCDs round-robin).  The live loop gives the detector -- a chain of ~80 short, narrow
+// launches -- its own CUs so that it never queues behind the pose network's full-chip grids (and vice versa).
+extern "C" int flope_stream_create_cu_mask(int device_id, const uint32_t* mask, int words, void** out_stream) {
+  if (!mask || words < 1 || words > 32 || !out_stream) return FLOPE_EINVAL;
+  *out_stream = nullptr;
+  bool any = false;
+  for (int i = 0; i < words; ++i) any = any || mask[i] != 0;
+  if (!any) return FLOPE_EINVAL;
+  if (hipSetDevice(device_id) != hipSuccess) return FLOPE_EHIP;
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); return FLOPE_EHIP; }
+  *out_stream = st;
+  return FLOPE_OK;
+}
+
+extern "C" int flope_stream_destroy(int device_id, void* stream) {
+  if (!stream) return FLOPE_OK;
+  if (hipSetDevice(device_id) != hipSuccess) return FLOPE_EHIP;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? FLOPE_OK : FLOPE_EHIP;
+}
+
 extern "C" const char* flope_version(void) { return "flope_amd 0.1 (gfx950; mfma_f32_16x16x32 bf16/f16; fp32 head)"; }
 
 extern "C" const char* flope_last_error(flope_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }

@@ -47,8 +47,8 @@ def write_detection_file(path, rows: np.ndarray) -> None:
 
 def live_pose_loop(predictor, frames, pipelined: bool = False):
     """frames: iterable of (rgb uint8 [H,W,3], depth uint16 [H,W]) -> list of float64 [N,4,4] | None.
-    pipelined: use the predictor's two-stream software pipeline (FastPosePredictor.iter_flower_poses: detector of frame
-    t + 1 beside the pose network of frame t); same results, higher frame rate."""
+    pipelined: use the predictor's software pipeline (FastPosePredictor.iter_flower_poses: uploads of frame t + 1, detector
+    of frame t and pose network of frame t - 1 on three streams); same results, higher frame rate."""
     if pipelined and hasattr(predictor, "iter_flower_poses"):
         return list(predictor.iter_flower_poses(frames))
     return [predictor.get_flower_poses(rgb, depth) for rgb, depth in frames]

@@ -145,51 +145,78 @@ class FastPosePredictor:
                                      device=self.device)
 
     def iter_flower_poses(self, frames):
-        """`get_flower_poses` over a stream of (rgb, depth) frames, software-pipelined: the detector of frame t + 1 runs on
-        one HIP stream while crops -> PoseResNet -> Procrustes of frame t run on another (the detector is a chain of short
-        kernels that leaves most of the GPU idle; the pose network fills it).  Yields exactly what get_flower_poses returns,
-        frame by frame, in order; a result becomes available one frame late.  The reference loop (scripts/live_pose.py:31-41)
-        is sequential; this is the same computation with two frames in flight."""
+        """`get_flower_poses` over a stream of (rgb, depth) frames, software-pipelined three deep.  While the host reads the
+        boxes of frame t - 1 and enqueues its crops -> PoseResNet -> Procrustes on one HIP stream, the detector of frame t
+        is already queued on another (the detector is a chain of short, narrow launches; the pose network fills what it leaves
+        idle: 0.88 + 0.79 ms alone, 1.29 ms side by side), and the uploads of frame t + 1 go through a third.  Yields exactly
+        what get_flower_poses returns, frame by frame, in order, two frames late.  The reference loop
+        (scripts/live_pose.py:31-41) is sequential; this is the same computation with three frames in flight."""
         if self.yolo is None:
             for rgb, depth in frames:
                 yield self.get_flower_poses(rgb, depth)
             return
         dev = torch.device(self.device)
-        s_det, s_pose = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        # (replaying the detector as a captured hipGraph here measured slower, 0.88 vs 0.78 of the sequential frame time: the
-        # per-frame critical path is detector GPU time + the host's box selection between the two stages, not launch work)
+        s_io, s_det, s_pose = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         H, W = self.yolo.frame_h, self.yolo.frame_w
-        copies = [(torch.empty((H, W, 3), dtype=torch.uint8, device=dev), torch.empty((H, W), dtype=torch.uint8, device=dev))
-                  for _ in range(2)]
-        pose_done = [None, None]               # pose stage finished reading copies[i]
-        pending, have_pending = None, False
+        NS = 3
+        slots = [dict(frame=torch.empty((H, W, 3), dtype=torch.uint8, device=dev), out=self.yolo.new_outputs(), depth=None,
+                      ready=None, pose_done=None, shape=None) for _ in range(NS)]
+
+        def stage_detect(t, rgb, depth):
+            sl = slots[t % NS]
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            if rgb.shape != (H, W, 3):
+                raise ValueError(f"expected a uint8 BGR frame [{H},{W},3], got {rgb.shape}")
+            with torch.cuda.stream(s_io):
+                if sl["pose_done"] is not None:
+                    s_io.wait_event(sl["pose_done"])        # the pose stage of frame t - NS has read this slot
+                sl["frame"].copy_(torch.from_numpy(rgb), non_blocking=True)
+                sl["depth"] = upload_depth(depth, dev)
+                sl["depth"].record_stream(s_pose)
+                up = torch.cuda.Event()
+                up.record(s_io)
+            sl["shape"] = rgb.shape
+            with torch.cuda.stream(s_det):
+                s_det.wait_event(up)
+                self.yolo.detect_device(sl["frame"], out=sl["out"], in_place=True)
+                sl["ready"] = torch.cuda.Event()
+                sl["ready"].record(s_det)
+
+        def read_boxes(t):
+            sl = slots[t % NS]
+            det, count, _ = sl["out"]
+            with torch.cuda.stream(s_io):               # a stream with nothing queued: waits for this frame's detector only
+                s_io.wait_event(sl["ready"])
+                n = int(count.item())
+                return det[:n, :4].cpu().numpy().astype(np.int16)          # fast_pose_predictor.py:55-56
+
+        def stage_pose(t, bb):
+            sl = slots[t % NS]
+            with torch.cuda.stream(s_pose):
+                s_pose.wait_event(sl["ready"])
+                packed = enqueue_poses(self.posenet, sl["shape"], bb, self.K, 1000.0, sl["frame"], sl["out"][2], sl["depth"], device=dev)
+                sl["pose_done"] = torch.cuda.Event()
+                sl["pose_done"].record(s_pose)
+            return packed
+
+        def finish(packed):
+            with torch.cuda.stream(s_pose):
+                return finish_poses(packed)
+
+        detecting, posing = [], []                     # frame indices in flight per stage (oldest first)
         for t, (rgb, depth) in enumerate(frames):
-            fb, mb = copies[t & 1]
-            with torch.cuda.stream(s_det):
-                det, count, mask_d, frame_d = self.yolo.detect_device(rgb)
-                if pose_done[t & 1] is not None:
-                    s_det.wait_event(pose_done[t & 1])
-                fb.copy_(frame_d, non_blocking=True)
-                mb.copy_(mask_d, non_blocking=True)
-                depth_d = upload_depth(depth, dev)
-                depth_d.record_stream(s_pose)
-                ready = torch.cuda.Event()
-                ready.record(s_det)
-            if have_pending:                   # frame t - 1: its device work overlapped the detector launched above
-                with torch.cuda.stream(s_pose):
-                    out = finish_poses(pending)
-                yield out
-            with torch.cuda.stream(s_det):
-                n = int(count.item())          # waits for the detector of frame t only
-                bb = det[:n, :4].cpu().numpy().astype(np.int16)
-            with torch.cuda.stream(s_pose):
-                s_pose.wait_event(ready)
-                pending = enqueue_poses(self.posenet, rgb.shape, bb, self.K, 1000.0, fb, mb, depth_d, device=dev)
-                have_pending = True
-                ev = torch.cuda.Event()
-                ev.record(s_pose)
-                pose_done[t & 1] = ev
-        if have_pending:
-            with torch.cuda.stream(s_pose):
-                out = finish_poses(pending)
-            yield out
+            stage_detect(t, rgb, depth)
+            detecting.append(t)
+            if len(detecting) == 2:                     # frame t - 1: its detector ran while this frame was uploaded and queued
+                u = detecting.pop(0)
+                bb = read_boxes(u)
+                if posing:
+                    yield finish(posing.pop(0))         # frame t - 2, before new pose work queues up behind it
+                posing.append(stage_pose(u, bb))
+        for u in detecting:
+            bb = read_boxes(u)
+            if posing:
+                yield finish(posing.pop(0))
+            posing.append(stage_pose(u, bb))
+        for packed in posing:
+            yield finish(packed)

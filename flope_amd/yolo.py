@@ -121,10 +121,29 @@ class YoloSeg:
         with torch.cuda.device(self.device):
             self._check(self.lib.flope_yolo_forward(self.handle, f.data_ptr(), self._stream()))
 
-    def detect_device(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET):
+    def new_outputs(self):
+        """a private (det, count, mask) buffer set for detect_device(out=...): several frames in flight"""
+        return (torch.zeros((MAX_DET, 8), dtype=torch.float32, device=self.device),
+                torch.zeros(1, dtype=torch.int32, device=self.device),
+                torch.zeros((self.frame_h, self.frame_w), dtype=torch.uint8, device=self.device))
+
+    def detect_device(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET, out=None, in_place: bool = False):
         """-> (det float32 [max_det,8], count int32 [1], mask uint8 [H,W], frame uint8 [H,W,3]): the engine's own device
-        buffers, valid until the next call.  Nothing is synchronised."""
-        f = self._frame(frame)
+        buffers, valid until the next call -- or the buffers of `out` (from new_outputs()).  in_place: `frame` is a device
+        tensor that stays untouched until the detector has run; it is read where it is.  Nothing is synchronised."""
+        if in_place:
+            if not (isinstance(frame, torch.Tensor) and frame.is_cuda and frame.dtype == torch.uint8 and frame.is_contiguous()
+                    and tuple(frame.shape) == (self.frame_h, self.frame_w, 3)):
+                raise ValueError(f"in_place needs a contiguous uint8 device frame [{self.frame_h},{self.frame_w},3]")
+            f = frame
+        else:
+            f = self._frame(frame)
+        det, count, mask = out if out is not None else (self._det, self._count, self._mask)
+        if out is not None and not (det.is_cuda and det.dtype == torch.float32 and tuple(det.shape) == (MAX_DET, 8) and det.is_contiguous()
+                                    and count.dtype == torch.int32 and count.numel() == 1 and count.is_cuda
+                                    and mask.is_cuda and mask.dtype == torch.uint8 and mask.is_contiguous()
+                                    and tuple(mask.shape) == (self.frame_h, self.frame_w)):
+            raise ValueError("out must come from new_outputs()")
         cur = torch.cuda.current_stream(self.device)
         st = cur
         if cur.cuda_stream == 0:
@@ -132,10 +151,10 @@ class YoloSeg:
             st.wait_stream(cur)
         with torch.cuda.device(self.device):
             self._check(self.lib.flope_yolo_detect(self.handle, f.data_ptr(), float(conf), float(iou), int(max_det),
-                                                   self._det.data_ptr(), self._count.data_ptr(), self._mask.data_ptr(), st.cuda_stream))
+                                                   det.data_ptr(), count.data_ptr(), mask.data_ptr(), st.cuda_stream))
         if st is not cur:
             cur.wait_stream(st)
-        return self._det, self._count, self._mask, f
+        return det, count, mask, f
 
     def detect(self, frame, conf: float = 0.25, iou: float = 0.7, max_det: int = MAX_DET):
         """-> (boxes float32 [n,4] frame xyxy, conf [n], cls [n], anchor [n], mask uint8 [H,W]) as numpy arrays."""

@@ -168,6 +168,11 @@ int flope_launch_info(flope_handle h, int idx, int batch, char* name, int name_c
 int flope_describe_plan(flope_handle h, char* buf, int buflen);
 /* library / build identification */
 const char* flope_version(void);
+/* A stream restricted to the compute units set in mask[words] (bit i of word i / 32 = CU i in the runtime's enumeration;
+ * hipExtStreamCreateWithCUMask).  Used by the live loop to give the detector and the pose network disjoint parts of the chip
+ * (FastPosePredictor.iter_flower_poses); any entry point of this library accepts such a stream. */
+int flope_stream_create_cu_mask(int device_id, const uint32_t* mask, int words, void** out_stream);
+int flope_stream_destroy(int device_id, void* stream);
 
 /* ---- TransformerEncoder (reference scripts/tf_encoder.py:5-27) -------------
  * Replaces `TransformerEncoder(input_dim, model_dim, out_dim, num_heads, num_layers, ff_dim,

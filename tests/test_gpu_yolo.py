@@ -248,8 +248,9 @@ def test_other_checkpoints_scale_s_and_several_classes(widths, nc, seed, H, W, i
 
 
 def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path):
-    """FastPosePredictor.iter_flower_poses (detector of frame t + 1 on one stream beside the pose network of frame t on
-    another, double-buffered frame / mask copies) returns, frame by frame, exactly what get_flower_poses returns."""
+    """FastPosePredictor.iter_flower_poses (three frames in flight: uploads, detector and pose network on three streams,
+    per-slot frame / mask / box buffers) returns, frame by frame, exactly what get_flower_poses returns -- for streams
+    shorter than, equal to and longer than the pipeline depth."""
     import yaml
     from flope_amd.harness import live_pose_loop
     from flope_amd.yolo_weights import synthetic_frame
@@ -262,19 +263,21 @@ def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path
     pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr))
     rng = np.random.default_rng(3)
     frames = []
-    for i in range(5):
+    for i in range(8):
         img = synthetic_frame(20 + i, H, W)
         depth = (400 + rng.normal(0, 4, (H, W))).astype(np.uint16)
         if i == 2:
             img = np.zeros_like(img)                  # a frame with nothing to detect in the middle of the stream
         frames.append((img, depth))
     seq = live_pose_loop(pred, frames)
-    pip = live_pose_loop(pred, frames, pipelined=True)
-    assert len(seq) == len(pip) == 5 and any(r is not None for r in seq)
-    for a, b in zip(seq, pip):
-        assert (a is None) == (b is None)
-        if a is not None:
-            assert np.array_equal(a, b)
+    assert any(r is not None for r in seq) and seq[2] is None
+    for n in (8, 1, 2, 3, 0):
+        pip = live_pose_loop(pred, frames[:n], pipelined=True)
+        assert len(pip) == n
+        for a, b in zip(seq, pip):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.array_equal(a, b)
 
 
 def test_yolo_error_paths(ysd):

@@ -59,7 +59,7 @@ def main_yolo(tmp, ckpt, intr):
     t0 = time.perf_counter()
     outs = list(pred.iter_flower_poses(frames))
     dp = (time.perf_counter() - t0) / len(frames)
-    print(f"[e2e+yolo, pipelined] detector of frame t+1 beside the pose network of frame t (two streams): "
+    print(f"[e2e+yolo, pipelined] uploads of frame t+1, detector of frame t, pose network of frame t-1 on three streams: "
           f"{dp*1e3:.2f} ms/frame, {1/dp:.1f} frames/s, {sum(0 if o is None else o.shape[0] for o in outs)/len(frames)/dp:.0f} poses/s", flush=True)
 
 
