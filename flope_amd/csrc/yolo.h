@@ -13,7 +13,7 @@ struct YConvP {
   const void* in;  int Hi, Wi, Cin, ldi;     // Cin % 8 == 0
   void* out;       int Ho, Wo, Cout, ldo;    // out_mode 1: float32 rows, ldo in floats
   const void* res; int ldr;                  // optional residual view, added AFTER the activation (nullptr = none)
-  const void* w;                             // [rows = ceil(Cout / (16 NT)) * 16 NT][Kp] 16-bit, rows permuted (pack_yconv)
+  const void* w;                             // 16-bit, MFMA A-fragment order [channel block][k step][NT][lane][8] (Builder::pack)
   const float* bias;                         // [rows]
   const void* zero;                          // >= 16 bytes of zeros
   int k, stride;                             // 1 or 3 (pad = k / 2); 1 or 2
@@ -24,6 +24,7 @@ struct YConvP {
   int ksteps;                                // Kp / 32
   int out_mode;                              // 0: 16-bit view, 1: float32 view, 2: 2x2 stride-2 transposed conv scatter (16-bit)
   int dc;                                    // out_mode 2: real output channels (rows = 4 * dc, row = (dy*2+dx)*dc + co)
+  int xcd;                                   // set by the launcher: workgroup order remapped so that an XCD owns an image band
 };
 
 struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU) (+ add)
@@ -41,8 +42,8 @@ constexpr int kYMultiMax = 8;
 struct YMultiOp {
   int code;                                  // 0..11: conv, (NT index 0/1/2) * 4 + (3x3 ? 2 : 0) + (split-K ? 1 : 0); 12: depthwise
   int nbx;                                   // conv: workgroups along pixels (local block b -> (b % nbx, b / nbx))
-  int start;                                 // first workgroup of this op in the grid
-  int pad_;
+  int start;                                 // first workgroup of this op in the grid (a multiple of 8)
+  int nblocks;                               // its workgroups; the grid pads every op to a multiple of 8
   union U { YConvP c; YDwP d; } u;
 };
 struct YMultiP { int n, total; YMultiOp op[kYMultiMax]; };

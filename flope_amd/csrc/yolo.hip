@@ -42,7 +42,6 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
   if (!SPLITK && m_base >= p.M) return;
   const int nblk = by;
   const int pad = K3 ? 1 : 0;
-  const size_t Kp2 = (size_t)p.ksteps * 64;          // bytes per weight row
   int iy0[MTW], ix0[MTW];
   bool pv[MTW];
 #pragma unroll
@@ -54,7 +53,9 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
     iy0[pt] = oy * p.stride - pad;
     ix0[pt] = ox * p.stride - pad;
   }
-  const char* const wrow = (const char*)p.w + (size_t)(nblk * CB + c16) * Kp2 + g * 16;
+  // weights are stored in fragment order [channel block][k step][channel tile][lane][16 B]: one wave-load = one contiguous
+  // KiB (8 cache lines; row-major rows put its 64 lanes on 64 different lines and the L1's tag rate became the bound)
+  const char* const wrow = (const char*)p.w + (size_t)nblk * p.ksteps * (NT * 1024) + lane * 16;
   const char* const in = (const char*)p.in;
   const char* const zero = (const char*)p.zero;
   const int ks0 = SPLITK ? (wave * p.ksteps) >> 2 : 0, ks1 = SPLITK ? ((wave + 1) * p.ksteps) >> 2 : p.ksteps;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
       tapok = kg < p.cg;
     }
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(wrow + (size_t)ct * 16 * Kp2 + (size_t)ks * 64);
+    for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(wrow + (size_t)(ks * NT + ct) * 1024);
 #pragma unroll
     for (int pt = 0; pt < MTW; ++pt) {
       const int iy = iy0[pt] + ky, ix = ix0[pt] + kx;
@@ -190,10 +191,24 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
   }
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (flat id mod 8), each XCD with its own 4 MiB L2.  On the large maps the
+// nine taps of a 3x3 conv re-read every input pixel nine times: with the natural order every XCD touches the whole map
+// (7.5 MB at 184 x 320 x 64) and the re-reads fall out of its L2.  Remapped, XCD x owns one contiguous run of tiles (an
+// image band): flat id b -> start(b mod 8) + b div 8 with start(x) = x * (n div 8) + min(x, n mod 8)  (a bijection on [0, n)).
+__device__ __forceinline__ int xcd_band(const int b, const int n) {
+  const int x = b & 7, q = n >> 3, r = n & 7;
+  return x * q + min(x, r) + (b >> 3);
+}
+
 template <typename T, int NT, bool K3, bool SPLITK>
 __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
   __shared__ float red[SPLITK ? 3 * 2 * NT * 4 * 64 : 1];
-  yconv_body<T, NT, K3, SPLITK>(p, blockIdx.x, blockIdx.y, red);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (!SPLITK && p.xcd) {
+    const int nbx = gridDim.x, lb = xcd_band(by * nbx + bx, nbx * gridDim.y);
+    by = lb / nbx; bx = lb - by * nbx;
+  }
+  yconv_body<T, NT, K3, SPLITK>(p, bx, by, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -248,8 +263,10 @@ __global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP P) {
   int s = 0;
   for (int i = 1; i < P.n; ++i) s = b >= P.op[i].start ? i : s;
   const YMultiOp& o = P.op[s];
-  const int lb = b - o.start;
+  int lb = b - o.start;                                   // op starts are multiples of 8: lb mod 8 is the XCD
+  if (lb >= o.nblocks) return;
   if (o.code == 12) { ydw_body<T>(o.u.d, lb); return; }
+  if (o.u.c.xcd) lb = xcd_band(lb, o.nblocks);
   const int by = lb / o.nbx, bx = lb - by * o.nbx;
   switch (o.code) {
     case 0: yconv_body<T, 1, false, false>(o.u.c, bx, by, red); break;
@@ -782,13 +799,20 @@ static bool yconv_geometry(const YConvP* p, int nt, bool* splitk, int* nbx, int*
   *nby = (rows + 16 * nt - 1) / (16 * nt);
   return true;
 }
+static bool yconv_wants_xcd_bands(const YConvP* p, bool splitk, int nbx, int nby, int mode) {
+  return mode != 0 && !splitk && nbx * nby >= 64 && (mode == 2 || p->k == 3);
+}
+static int g_xcd_mode = 0;                                   // 0 never, 1 3x3 convs on >= 64 workgroups, 2 those and 1x1 convs
+extern "C" int flope_yconv_xcd_mode(int mode) { const int prev = g_xcd_mode; if (mode >= 0 && mode <= 2) g_xcd_mode = mode; return prev; }
 
 // nt = channel tiles of 16 per workgroup column (1, 2 or 4): rows of p->w / p->bias = ceil(Cout / (16 nt)) * 16 nt
 extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stream) {
   bool splitk; int nbx, nby;
   if (!yconv_geometry(p, nt, &splitk, &nbx, &nby)) return (int)hipErrorInvalidValue;
   const dim3 grid(nbx, nby);
-  if (dtype == 0) yconv_go<bf16_t>(*p, nt, splitk, grid, (hipStream_t)stream); else yconv_go<f16_t>(*p, nt, splitk, grid, (hipStream_t)stream);
+  YConvP q = *p;
+  q.xcd = yconv_wants_xcd_bands(p, splitk, nbx, nby, g_xcd_mode) ? 1 : 0;
+  if (dtype == 0) yconv_go<bf16_t>(q, nt, splitk, grid, (hipStream_t)stream); else yconv_go<f16_t>(q, nt, splitk, grid, (hipStream_t)stream);
   return (int)hipGetLastError();
 }
 
@@ -798,16 +822,17 @@ extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt) {
   if (m->n >= kYMultiMax || !yconv_geometry(p, nt, &splitk, &nbx, &nby)) return (int)hipErrorInvalidValue;
   YMultiOp& o = m->op[m->n++];
   o.code = (nt == 1 ? 0 : nt == 2 ? 4 : 8) + (p->k == 3 ? 2 : 0) + (splitk ? 1 : 0);
-  o.nbx = nbx; o.start = m->total; o.u.c = *p;
-  m->total += nbx * nby;
+  o.nbx = nbx; o.start = m->total; o.nblocks = nbx * nby; o.u.c = *p;
+  o.u.c.xcd = yconv_wants_xcd_bands(p, splitk, nbx, nby, g_xcd_mode) ? 1 : 0;
+  m->total += (o.nblocks + 7) / 8 * 8;
   return 0;
 }
 
 extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p) {
   if (m->n >= kYMultiMax || p->C % 8) return (int)hipErrorInvalidValue;
   YMultiOp& o = m->op[m->n++];
-  o.code = 12; o.nbx = 1; o.start = m->total; o.u.d = *p;
-  m->total += (p->H * p->W * (p->C / 8) + 255) / 256;
+  o.code = 12; o.nbx = 1; o.start = m->total; o.nblocks = (p->H * p->W * (p->C / 8) + 255) / 256; o.u.d = *p;
+  m->total += (o.nblocks + 7) / 8 * 8;
   return 0;
 }
 

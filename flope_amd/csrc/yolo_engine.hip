@@ -26,6 +26,7 @@ extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream);
 extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt);
 extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p);
 extern "C" int flope_ymulti_launch(const YMultiP* m, int dtype, void* stream);
+extern "C" int flope_yconv_xcd_mode(int mode);
 extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream);
 extern "C" int flope_yup_launch(const YUpP* p, void* stream);
 extern "C" int flope_yattn_init();
@@ -174,20 +175,24 @@ struct Builder {
   }
 
   // folded weights wf[cout][cin][k][k] + bias -> device images of yconv_kernel: rows padded to 16*nt and permuted so that
-  // MFMA D rows 4g..4g+3 of channel tile ct are channels g*4nt + 4ct .. +3; k = tap * cin_pad + ci, zero padded to 32
+  // MFMA D rows 4g..4g+3 of channel tile ct are channels g*4nt + 4ct .. +3; k = tap * cin_pad + ci, zero padded to 32;
+  // stored in MFMA A-fragment order [channel block][k step][channel tile][lane = kq * 16 + row][8 k]: a wave-load is 1 KiB
   void pack(const std::vector<float>& wf, const std::vector<float>& bf, int cout_, int cin, int cin_pad, int k, int nt,
             const void** w_dev, const float** b_dev, int* ksteps) {
     const int CB = 16 * nt, rows = (cout_ + CB - 1) / CB * CB, K = k * k * cin_pad, Kp = (K + 31) / 32 * 32;
     std::vector<uint16_t> w((size_t)rows * Kp, 0);
     std::vector<float> b(rows, 0.f);
+    const int ks_n = Kp / 32;
     for (int r = 0; r < rows; ++r) {
       const int blk = r / CB, in = r % CB, ct = in / 16, rr = in % 16, g = rr >> 2, q = rr & 3;
       const int co = blk * CB + g * 4 * nt + ct * 4 + q;
       if (co >= cout_) continue;
       b[r] = bf[co];
       for (int tap = 0; tap < k * k; ++tap)
-        for (int ci = 0; ci < cin; ++ci)
-          w[(size_t)r * Kp + (size_t)tap * cin_pad + ci] = cvt16(wf[((size_t)co * cin + ci) * k * k + tap], e->dtype);
+        for (int ci = 0; ci < cin; ++ci) {
+          const int kk = tap * cin_pad + ci, ks = kk / 32, kq = (kk % 32) / 8, kr = kk % 8;
+          w[((((size_t)blk * ks_n + ks) * nt + ct) * 64 + kq * 16 + rr) * 8 + kr] = cvt16(wf[((size_t)co * cin + ci) * k * k + tap], e->dtype);
+        }
     }
     *w_dev = upload(w); *b_dev = (const float*)upload(b); *ksteps = Kp / 32;
   }
@@ -741,6 +746,11 @@ extern "C" int flope_yolo_read_tensor(flope_yolo_handle e, const char* name, flo
 extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int value) {
   if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
+  if (!strcmp(name, "xcd")) {                      // process-wide A/B knob; the batched schedule bakes it in at load time
+    const int prev = flope_yconv_xcd_mode(value);
+    if (e->loaded) { if (int rc = build_schedules(e)) return rc; if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; } }
+    return prev;
+  }
   if (!strcmp(name, "batch")) { const int prev = e->opt_batch; e->opt_batch = value != 0; return prev; }
   if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=0, help="run only this many detects (for rocprofv3)")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1, help="0: one launch per op in program order")
+    ap.add_argument("--xcd", type=int, default=-1, help="XCD band remap of conv workgroups: 0 never, 1 3x3 convs (default), 2 also 1x1")
     ap.add_argument("--per-launch", action="store_true", help="print the per-launch time table (HIP events) and exit")
     args = ap.parse_args()
     from flope_amd.yolo import YoloSeg
@@ -27,6 +28,8 @@ def main():
     y.load_state_dict(synthetic_yolo_state_dict(0))
     y.set_option("graph", args.graph)
     y.set_option("batch", args.batch)
+    if args.xcd >= 0:
+        y.set_option("xcd", args.xcd)
     frame = torch.from_numpy(synthetic_frame(0)).cuda()
     if args.per_launch:
         print(y.profile(frame, 20))
