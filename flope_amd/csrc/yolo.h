@@ -25,6 +25,8 @@ struct YConvP {
   int out_mode;                              // 0: 16-bit view, 1: float32 view, 2: 2x2 stride-2 transposed conv scatter (16-bit)
   int dc;                                    // out_mode 2: real output channels (rows = 4 * dc, row = (dy*2+dx)*dc + co)
   int xcd;                                   // set by the launcher: workgroup order remapped so that an XCD owns an image band
+  int tile, tiles_x;                         // set by the launcher: LDS-staged 8 x 16 output tiles; tiles per row
+  unsigned pw_mg, pw_sh;                     // n / (patch width) as multiply-shift
 };
 
 struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU) (+ add)
@@ -46,9 +48,10 @@ struct YMultiOp {
   int nblocks;                               // its workgroups; the grid pads every op to a multiple of 8
   union U { YConvP c; YDwP d; } u;
 };
-struct YMultiP { int n, total; YMultiOp op[kYMultiMax]; };
+struct YMultiP { int n, total, lds, pad_; YMultiOp op[kYMultiMax]; };
 
-struct YPoolP { const void* in; int H, W, C, ldi; void* out; int ldo; };           // 5x5 s1 p2 max-pool, -inf border
+struct YPoolP { const void* in; int H, W, C, ldi; void* out; int ldo; int n; };    // n (1..3) cascaded 5x5 s1 p2 max-pools, -inf border;
+                                                                                   // result i -> channels [i C, (i+1) C) of out
 struct YUpP { const void* in; int H, W, C, ldi; void* out; int ldo; };             // nearest 2x: out is [2H][2W]
 
 struct YAttnP {          // ultralytics Attention: per head q(32) k(32) v(64) interleaved in the qkv map

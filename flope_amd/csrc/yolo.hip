@@ -16,6 +16,7 @@
 //   ymask_*          ops.process_mask + the sum/clip/x255 of get_bbox_mask
 #include "common.h"
 #include "yolo.h"
+#include "host_pack.h"
 
 #include <algorithm>
 
@@ -24,6 +25,69 @@ namespace {
 __device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
 
 template <typename T> __device__ __forceinline__ float ld16(const void* p) { return to_f32<T>(*(const T*)p); }
+
+// ---- epilogue: this lane = one pixel (flat index mm[pt]) of each tile x channels ch0 .. ch0 + 4 NT - 1
+template <typename T, int NT, int MTW>
+__device__ __forceinline__ void yconv_epilogue(const YConvP& p, const int nblk, const int g, const int (&mm)[MTW], const bool (&pv)[MTW],
+                                               const f32x4 (&acc)[MTW][NT]) {
+  constexpr int CB = 16 * NT;
+  const int ch0 = nblk * CB + g * 4 * NT;
+#pragma unroll
+  for (int pt = 0; pt < MTW; ++pt) {
+    if (!pv[pt]) continue;
+    const int m = mm[pt];
+    float v[4 * NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = acc[pt][ct][q];
+        v[ct * 4 + q] = p.act ? silu(a) : a;
+      }
+    if (p.out_mode == 1) {                             // float32 prediction rows (Detect / Segment heads)
+      float* o = (float*)p.out + (size_t)m * p.ldo;
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i)
+        if (ch0 + i < p.Cout) o[ch0 + i] = v[i];
+      continue;
+    }
+    size_t opix;
+    int och = ch0;
+    if (p.out_mode == 2) {                             // ConvTranspose2d 2x2 s2: row block -> (dy, dx) quadrant
+      const int quad = (nblk * CB) / p.dc;
+      const int oy = m / p.Wo, ox = m - oy * p.Wo;
+      opix = (size_t)(2 * oy + (quad >> 1)) * (2 * p.Wo) + 2 * ox + (quad & 1);
+      och = ch0 - quad * p.dc;
+    } else {
+      opix = (size_t)m;
+    }
+    char* o = (char*)p.out + (opix * p.ldo + och) * 2;
+    const bool full = p.out_mode == 2 || ch0 + 4 * NT <= p.Cout;
+    if (full) {
+      if (p.res) {
+        const char* r = (const char*)p.res + ((size_t)m * p.ldr + ch0) * 2;
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) v[i] += ld16<T>(r + i * 2);
+      }
+      unsigned w[2 * NT];
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) w[i] = pk_out16<T>(pack2<T>(v[2 * i], v[2 * i + 1]), false);
+      if constexpr (NT == 1) *(u32x2*)o = u32x2{w[0], w[1]};
+      else {
+#pragma unroll
+        for (int i = 0; i < NT / 2; ++i) *(u32x4*)(o + i * 16) = u32x4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i)
+        if (ch0 + i < p.Cout) {
+          float x = v[i];
+          if (p.res) x += ld16<T>((const char*)p.res + ((size_t)m * p.ldr + ch0 + i) * 2);
+          *(T*)(o + i * 2) = from_f32<T>(x);
+        }
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // SPLITK: the four waves of a workgroup share ONE 32-pixel tile and each walks a quarter of the K steps; partial sums
@@ -132,63 +196,120 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[pt][ct][q] += red[(w * RW + (pt * NT + ct) * 4 + q) * 64 + lane];
   }
-  // ---- epilogue: this lane = pixel c16 of each tile x channels ch0 .. ch0 + 4 NT - 1
-  const int ch0 = nblk * CB + g * 4 * NT;
+  int mm[MTW];
 #pragma unroll
-  for (int pt = 0; pt < MTW; ++pt) {
-    if (!pv[pt]) continue;
-    const int m = m_base + pt * 16 + c16;
-    float v[4 * NT];
+  for (int pt = 0; pt < MTW; ++pt) mm[pt] = m_base + pt * 16 + c16;
+  yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Large maps (everything that is not SPLITK): one workgroup = an 8-row x 16-column tile of output pixels, wave w owns rows
+// 2w and 2w+1.  The input patch ((7 s + k) x (15 s + k) pixels, all channels) is staged once into LDS with fully coalesced
+// 16-byte loads (consecutive lanes = consecutive channels, then pixels) and the taps read their B fragments from there:
+// fetched straight from global memory, the 16 pixels of a fragment load sit on 16 different cache lines (64 tag look-ups per
+// wave-load), every input pixel is fetched nine times, and the L1's tag rate -- not bytes, not MFMA -- bounded these layers.
+// Pixel pitch in LDS = Cin * 2 + 16 bytes: the 16 lanes of a ds_read_b128 group land on 16 different bank quads.
+template <typename T, int NT, bool K3>
+__device__ __forceinline__ void yconv_tile_body(const YConvP& p, const int bx, const int by, char* const lds) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int MTW = 2, PD = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;
+  const int s = p.stride, pad = K3 ? 1 : 0, kk = K3 ? 3 : 1;
+  const int PW = 15 * s + kk, PH = 7 * s + kk;
+  const int iy00 = ty * 8 * s - pad, ix00 = tx * 16 * s - pad;
+  const int pitch = p.Cin * 2 + 16;
+  const int nblk = by;
+  const char* const wrow = (const char*)p.w + (size_t)nblk * p.ksteps * (NT * 1024) + lane * 16;
+  const int klast = p.ksteps - 1;
+  frag wf[PD][NT];
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+  for (int s_ = 0; s_ < PD; ++s_)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a = acc[pt][ct][q];
-        v[ct * 4 + q] = p.act ? silu(a) : a;
+    for (int ct = 0; ct < NT; ++ct) wf[s_][ct] = *(const frag*)(wrow + (size_t)(min(s_, klast) * NT + ct) * 1024);
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const f32x4 b = *(const f32x4*)(p.bias + nblk * (16 * NT) + ct * 16 + g * 4);
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt) acc[pt][ct] = b;
+  }
+  // ---- stage the patch (out-of-map pixels as zeros)
+  {
+    const int total = PH * PW * p.cg;
+    const char* const in = (const char*)p.in;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+      u32x4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 256;
+        const int pp = fastdiv(min(i, total - 1), p.cg_mg, p.cg_sh), c8 = min(i, total - 1) - pp * p.cg;
+        const int py = fastdiv(pp, p.pw_mg, p.pw_sh), px = pp - py * PW;
+        const int iy = iy00 + py, ix = ix00 + px;
+        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        v[j] = ok ? *(const u32x4*)(in + ((size_t)(iy * p.Wi + ix) * p.ldi + c8 * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+        dst[j] = i < total ? pp * pitch + c8 * 16 : -1;
       }
-    if (p.out_mode == 1) {                             // float32 prediction rows (Detect / Segment heads)
-      float* o = (float*)p.out + (size_t)m * p.ldo;
 #pragma unroll
-      for (int i = 0; i < 4 * NT; ++i)
-        if (ch0 + i < p.Cout) o[ch0 + i] = v[i];
-      continue;
-    }
-    size_t opix;
-    int och = ch0;
-    if (p.out_mode == 2) {                             // ConvTranspose2d 2x2 s2: row block -> (dy, dx) quadrant
-      const int quad = (nblk * CB) / p.dc;
-      const int oy = m / p.Wo, ox = m - oy * p.Wo;
-      opix = (size_t)(2 * oy + (quad >> 1)) * (2 * p.Wo) + 2 * ox + (quad & 1);
-      och = ch0 - quad * p.dc;
-    } else {
-      opix = (size_t)m;
-    }
-    char* o = (char*)p.out + (opix * p.ldo + och) * 2;
-    const bool full = p.out_mode == 2 || ch0 + 4 * NT <= p.Cout;
-    if (full) {
-      if (p.res) {
-        const char* r = (const char*)p.res + ((size_t)m * p.ldr + ch0) * 2;
-#pragma unroll
-        for (int i = 0; i < 4 * NT; ++i) v[i] += ld16<T>(r + i * 2);
-      }
-      unsigned w[2 * NT];
-#pragma unroll
-      for (int i = 0; i < 2 * NT; ++i) w[i] = pk_out16<T>(pack2<T>(v[2 * i], v[2 * i + 1]), false);
-      if constexpr (NT == 1) *(u32x2*)o = u32x2{w[0], w[1]};
-      else {
-#pragma unroll
-        for (int i = 0; i < NT / 2; ++i) *(u32x4*)(o + i * 16) = u32x4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4 * NT; ++i)
-        if (ch0 + i < p.Cout) {
-          float x = v[i];
-          if (p.res) x += ld16<T>((const char*)p.res + ((size_t)m * p.ldr + ch0 + i) * 2);
-          *(T*)(o + i * 2) = from_f32<T>(x);
-        }
+      for (int j = 0; j < 4; ++j)
+        if (dst[j] >= 0) *(u32x4*)(lds + dst[j]) = v[j];
     }
   }
+  __syncthreads();
+  // ---- K loop: B fragments from LDS (one step ahead), A fragments from global memory (PD steps ahead)
+  const int prow = (wave * 2 * s) * PW + c16 * s;                       // patch pixel of (tile row 2w, column c16), tap (0, 0)
+  auto xload = [&](int ks, frag (&xf)[MTW]) {
+    const int kg = ks * 4 + g;
+    int c8, ky = 0, kx = 0;
+    bool tapok;
+    if (K3) {
+      const int tap = fastdiv(kg, p.cg_mg, p.cg_sh);
+      c8 = kg - tap * p.cg;
+      ky = (tap * 11) >> 5;
+      kx = tap - 3 * ky;
+      tapok = tap < 9;
+    } else {
+      c8 = kg;
+      tapok = kg < p.cg;
+    }
+    const int off = tapok ? (prow + ky * PW + kx) * pitch + c8 * 16 : 0;
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt) {
+      frag f = *(const frag*)(lds + off + pt * (s * PW) * pitch);
+      if (!tapok) f = frag{};                                             // K padding: the weights are zero there, LDS is not
+      xf[pt] = f;
+    }
+  };
+  frag xa[MTW], xb[MTW];
+  xload(0, xa);
+  for (int ks = 0; ks < p.ksteps; ks += PD) {
+#pragma unroll
+    for (int s_ = 0; s_ < PD; ++s_) {
+      frag (&cur)[MTW] = (s_ & 1) ? xb : xa;
+      frag (&nxt)[MTW] = (s_ & 1) ? xa : xb;
+      if (ks + s_ < p.ksteps) {
+        xload(min(ks + s_ + 1, klast), nxt);
+#pragma unroll
+        for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[s_][ct], cur[pt], acc[pt][ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) wf[s_][ct] = *(const frag*)(wrow + (size_t)(min(ks + s_ + PD, klast) * NT + ct) * 1024);
+    }
+  }
+  int mm[MTW];
+  bool pv[MTW];
+  const int ox = tx * 16 + c16;
+#pragma unroll
+  for (int pt = 0; pt < MTW; ++pt) {
+    const int oy = ty * 8 + wave * 2 + pt;
+    pv[pt] = oy < p.Ho && ox < p.Wo;
+    mm[pt] = oy * p.Wo + ox;
+  }
+  yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
 }
 
 // Workgroups are handed to the 8 XCDs round-robin (flat id mod 8), each XCD with its own 4 MiB L2.  On the large maps the
@@ -202,13 +323,16 @@ __device__ __forceinline__ int xcd_band(const int b, const int n) {
 
 template <typename T, int NT, bool K3, bool SPLITK>
 __global__ __launch_bounds__(256) void yconv_kernel(const YConvP p) {
-  __shared__ float red[SPLITK ? 3 * 2 * NT * 4 * 64 : 1];
+  extern __shared__ __attribute__((aligned(16))) char ylds[];        // SPLITK: combine scratch; tile path: the input patch
   int bx = blockIdx.x, by = blockIdx.y;
   if (!SPLITK && p.xcd) {
     const int nbx = gridDim.x, lb = xcd_band(by * nbx + bx, nbx * gridDim.y);
     by = lb / nbx; bx = lb - by * nbx;
   }
-  yconv_body<T, NT, K3, SPLITK>(p, bx, by, red);
+  if constexpr (!SPLITK) {
+    if (p.tile) { yconv_tile_body<T, NT, K3>(p, bx, by, ylds); return; }
+  }
+  yconv_body<T, NT, K3, SPLITK>(p, bx, by, (float*)ylds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -255,10 +379,12 @@ __global__ __launch_bounds__(256) void ydw_kernel(const YDwP p) { ydw_body<T>(p,
 // Several INDEPENDENT launches of the graph in one grid (the Segment head's box / class / coefficient branches, the Proto
 // block beside them, the two 1x1 convs of a C3k that read the same map ...): every one of them is a few dozen workgroups with
 // a serial K loop, far too small to fill 256 CUs, and each costs a whole dependent launch when queued alone.  Workgroup b
-// belongs to op s with start[s] <= b < start[s+1]; the op's parameters are read from the kernel arguments (uniform).
+// belongs to op s with start[s] <= b < start[s+1]; the op's parameters are read from a table in device memory (uniform).
 template <typename T>
-__global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP P) {
-  __shared__ float red[3 * 2 * 4 * 4 * 64];
+__global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP* __restrict__ Pd) {
+  extern __shared__ __attribute__((aligned(16))) char ylds[];        // max over the ops: combine scratch / input patch
+  float* const red = (float*)ylds;
+  const YMultiP& P = *Pd;                                              // device memory, read with scalar loads (uniform)
   const int b = blockIdx.x;
   int s = 0;
   for (int i = 1; i < P.n; ++i) s = b >= P.op[i].start ? i : s;
@@ -268,6 +394,17 @@ __global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP P) {
   if (o.code == 12) { ydw_body<T>(o.u.d, lb); return; }
   if (o.u.c.xcd) lb = xcd_band(lb, o.nblocks);
   const int by = lb / o.nbx, bx = lb - by * o.nbx;
+  if (o.u.c.tile) {
+    switch (o.code) {
+      case 0: yconv_tile_body<T, 1, false>(o.u.c, bx, by, ylds); break;
+      case 2: yconv_tile_body<T, 1, true>(o.u.c, bx, by, ylds); break;
+      case 4: yconv_tile_body<T, 2, false>(o.u.c, bx, by, ylds); break;
+      case 6: yconv_tile_body<T, 2, true>(o.u.c, bx, by, ylds); break;
+      case 8: yconv_tile_body<T, 4, false>(o.u.c, bx, by, ylds); break;
+      default: yconv_tile_body<T, 4, true>(o.u.c, bx, by, ylds); break;
+    }
+    return;
+  }
   switch (o.code) {
     case 0: yconv_body<T, 1, false, false>(o.u.c, bx, by, red); break;
     case 1: yconv_body<T, 1, false, true>(o.u.c, bx, by, red); break;
@@ -284,6 +421,9 @@ __global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP P) {
   }
 }
 
+// SPPF: n cascaded 5x5 stride-1 max-pools (-inf border) of one map in one launch.  pool5 applied i+1 times is the maximum
+// over the (4 i + 5)^2 window clipped to the map, so the n results are ring-wise maxima of one 13 x 13 sweep (n = 3); result i
+// goes to channels [i C, (i + 1) C) of `out` (the concat buffer of SPPF.cv2).
 template <typename T>
 __global__ __launch_bounds__(256) void ypool_kernel(const YPoolP p) {
   const int c8n = p.C >> 3;
@@ -291,21 +431,82 @@ __global__ __launch_bounds__(256) void ypool_kernel(const YPoolP p) {
   if (idx >= p.H * p.W * c8n) return;
   const int pix = idx / c8n, c0 = (idx - pix * c8n) * 8;
   const int y = pix / p.W, x = pix - y * p.W;
-  float a[8];
+  constexpr float kNegInf = -3.0e38f;
+  float a[3][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = -3.0e38f;
-  for (int dy = -2; dy <= 2; ++dy)
-    for (int dx = -2; dx <= 2; ++dx) {
-      const int iy = y + dy, ix = x + dx;
-      if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[r][i] = kNegInf;
+  const int R = 2 * p.n;
+  for (int dy = -R; dy <= R; ++dy) {
+    const int iy = y + dy;
+    if ((unsigned)iy >= (unsigned)p.H) continue;
+    const int ry = dy < 0 ? -dy : dy;
+    for (int dx = -R; dx <= R; ++dx) {
+      const int ix = x + dx;
+      if ((unsigned)ix >= (unsigned)p.W) continue;
+      const int rx = dx < 0 ? -dx : dx, ring = ry > rx ? ry : rx;
       const u32x4 v = *(const u32x4*)((const char*)p.in + ((size_t)(iy * p.W + ix) * p.ldi + c0) * 2);
+      float f[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { a[2 * q] = fmaxf(a[2 * q], unpack_lo<T>(v[q])); a[2 * q + 1] = fmaxf(a[2 * q + 1], unpack_hi<T>(v[q])); }
+      for (int q = 0; q < 4; ++q) { f[2 * q] = unpack_lo<T>(v[q]); f[2 * q + 1] = unpack_hi<T>(v[q]); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        a[2][i] = fmaxf(a[2][i], f[i]);
+        if (ring <= 4) a[1][i] = fmaxf(a[1][i], f[i]);
+        if (ring <= 2) a[0][i] = fmaxf(a[0][i], f[i]);
+      }
     }
-  u32x4 o;
+  }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) o[q] = pack2<T>(a[2 * q], a[2 * q + 1]);
-  *(u32x4*)((char*)p.out + ((size_t)pix * p.ldo + c0) * 2) = o;
+  for (int r = 0; r < 3; ++r) {
+    if (r >= p.n) break;
+    // windows of radius 2 (r + 1): a[0] always holds ring <= 2, a[1] ring <= 4, a[2] everything swept (ring <= 2 n)
+    const float* src = (r == p.n - 1) ? a[2] : a[r];
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack2<T>(src[2 * q], src[2 * q + 1]);
+    *(u32x4*)((char*)p.out + ((size_t)pix * p.ldo + r * p.C + c0) * 2) = o;
+  }
+}
+
+// The same in LDS for maps that fit (2 x H W x 16 bytes): one workgroup = 8 channels of the whole map; each pool is a row pass
+// and a column pass over LDS (5 reads per element and pass instead of 169 dependent global loads per thread), results
+// streamed out after every column pass.  The ring kernel above stays as the fallback for larger maps.
+template <typename T>
+__global__ __launch_bounds__(256) void ysppf_lds_kernel(const YPoolP p) {
+  extern __shared__ __attribute__((aligned(16))) char ylds[];
+  const int HW = p.H * p.W, tid = threadIdx.x, c0 = blockIdx.x * 8;
+  u32x4* const A = (u32x4*)ylds;
+  u32x4* const B = A + HW;
+  for (int i = tid; i < HW; i += 256) A[i] = *(const u32x4*)((const char*)p.in + ((size_t)i * p.ldi + c0) * 2);
+  auto vmax = [](const u32x4& a, const u32x4& b) {
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack2<T>(fmaxf(unpack_lo<T>(a[q]), unpack_lo<T>(b[q])), fmaxf(unpack_hi<T>(a[q]), unpack_hi<T>(b[q])));
+    return o;
+  };
+  for (int r = 0; r < p.n; ++r) {
+    __syncthreads();
+    for (int i = tid; i < HW; i += 256) {
+      const int y = i / p.W, x = i - y * p.W;
+      u32x4 m = A[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d)
+        if (d != 0 && (unsigned)(x + d) < (unsigned)p.W) m = vmax(m, A[i + d]);
+      B[i] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < HW; i += 256) {
+      const int y = i / p.W;
+      u32x4 m = B[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d)
+        if (d != 0 && (unsigned)(y + d) < (unsigned)p.H) m = vmax(m, B[i + d * p.W]);
+      A[i] = m;
+      *(u32x4*)((char*)p.out + ((size_t)i * p.ldo + r * p.C + c0) * 2) = m;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void yup_kernel(const YUpP p) {
@@ -417,10 +618,24 @@ __global__ __launch_bounds__(256) void yattn_mfma_kernel(const YAttnP p) {
   for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -3.0e38f, l = 0.f;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int blk = 0; blk < NB; ++blk) {
+  // K rows three key blocks ahead (a block per iteration otherwise exposes one L2 round trip: 29 of them at 920 tokens)
+  constexpr int KPD = 3;
+  frag kq[KPD][2];
+  auto kload = [&](int blk, frag (&d)[2]) {
+    const int kb_ = min(blk, NB - 1) * 32;
+    d[0] = *(const frag*)(base + (size_t)min(kb_ + c16, p.N - 1) * ldB + 64 + g * 16);
+    d[1] = *(const frag*)(base + (size_t)min(kb_ + 16 + c16, p.N - 1) * ldB + 64 + g * 16);
+  };
+#pragma unroll
+  for (int i = 0; i < KPD; ++i) kload(i, kq[i]);
+  for (int blk0 = 0; blk0 < NB; blk0 += KPD) {
+#pragma unroll
+   for (int bi = 0; bi < KPD; ++bi) {
+    const int blk = blk0 + bi;
+    if (blk >= NB) break;
     const int kbase = blk * 32;
-    const frag ka = *(const frag*)(base + (size_t)min(kbase + c16, p.N - 1) * ldB + 64 + g * 16);
-    const frag kb = *(const frag*)(base + (size_t)min(kbase + 16 + c16, p.N - 1) * ldB + 64 + g * 16);
+    const frag ka = kq[bi][0], kb = kq[bi][1];
+    kload(blk + KPD, kq[bi]);
     f32x4 s0 = Elem<T>::mfma(ka, qf, z4), s1 = Elem<T>::mfma(kb, qf, z4);    // s0[r]: key kbase + 4g + r, query q0 + c16
     float mx = -3.0e38f;
 #pragma unroll
@@ -448,6 +663,7 @@ __global__ __launch_bounds__(256) void yattn_mfma_kernel(const YAttnP p) {
       for (int r = 0; r < 4; ++r) o[t][r] *= alpha;
       o[t] = Elem<T>::mfma(vf, pf, o[t]);                                      // D[dim t*16 + 4g + r][query c16]
     }
+   }
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -777,26 +993,44 @@ extern "C" int flope_yread_launch(const void* src, int kind, int H, int W, int C
   } while (0)
 
 template <typename T>
-static void yconv_go(const YConvP& p, int nt, bool splitk, dim3 grid, hipStream_t st) {
+static void yconv_go(const YConvP& p, int nt, bool splitk, dim3 grid, int lds, hipStream_t st) {
   const bool k3 = p.k == 3;
-#define GO(NT_)                                                                                            \
-  do {                                                                                                     \
-    if (k3 && splitk) hipLaunchKernelGGL((yconv_kernel<T, NT_, true, true>), grid, dim3(256), 0, st, p);   \
-    else if (k3) hipLaunchKernelGGL((yconv_kernel<T, NT_, true, false>), grid, dim3(256), 0, st, p);       \
-    else if (splitk) hipLaunchKernelGGL((yconv_kernel<T, NT_, false, true>), grid, dim3(256), 0, st, p);   \
-    else hipLaunchKernelGGL((yconv_kernel<T, NT_, false, false>), grid, dim3(256), 0, st, p);              \
+#define GO(NT_)                                                                                              \
+  do {                                                                                                       \
+    if (k3 && splitk) hipLaunchKernelGGL((yconv_kernel<T, NT_, true, true>), grid, dim3(256), lds, st, p);   \
+    else if (k3) hipLaunchKernelGGL((yconv_kernel<T, NT_, true, false>), grid, dim3(256), lds, st, p);       \
+    else if (splitk) hipLaunchKernelGGL((yconv_kernel<T, NT_, false, true>), grid, dim3(256), lds, st, p);   \
+    else hipLaunchKernelGGL((yconv_kernel<T, NT_, false, false>), grid, dim3(256), lds, st, p);              \
   } while (0)
   if (nt == 1) GO(1); else if (nt == 2) GO(2); else GO(4);
 #undef GO
 }
 
-static bool yconv_geometry(const YConvP* p, int nt, bool* splitk, int* nbx, int* nby) {
+static int g_splitk_max_m = 8192;                           // split-K (one 32-pixel tile per workgroup, K over its 4 waves) up to this map size
+extern "C" int flope_yconv_splitk_max_m(int m) { const int prev = g_splitk_max_m; if (m >= 0) g_splitk_max_m = m; return prev; }
+static int g_tile_mode = 1;                                  // 1: LDS-staged 8 x 16 tiles for every non-split-K conv; 0: fragments from global
+extern "C" int flope_yconv_tile_mode(int mode) { const int prev = g_tile_mode; if (mode == 0 || mode == 1) g_tile_mode = mode; return prev; }
+constexpr int kYTileLdsMax = 96 * 1024;
+
+// fills the launch-derived fields of *q (tile, tiles_x, pw_*), -> split-K?, grid, dynamic LDS bytes
+static bool yconv_geometry(const YConvP* p, int nt, YConvP* q, bool* splitk, int* nbx, int* nby, int* lds) {
   if ((p->k != 1 && p->k != 3) || p->Cin % 8 || (nt != 1 && nt != 2 && nt != 4) || p->M < 1) return false;
   const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
   if (p->out_mode == 2 && (p->dc % (16 * nt) || p->res)) return false;
-  *splitk = p->M <= 16384 && p->ksteps >= 8;                 // small map, long K: one tile per workgroup, K over its 4 waves
-  *nbx = *splitk ? (p->M + 31) / 32 : (p->M + 127) / 128;
+  *q = *p;
+  *splitk = p->M <= g_splitk_max_m && p->ksteps >= 8;        // small map, long K: one tile per workgroup, K over its 4 waves
   *nby = (rows + 16 * nt - 1) / (16 * nt);
+  const int PW = 15 * p->stride + p->k, PH = 7 * p->stride + p->k, patch = PH * PW * (p->Cin * 2 + 16);
+  q->tile = (!*splitk && g_tile_mode && patch <= kYTileLdsMax) ? 1 : 0;
+  if (q->tile) {
+    q->tiles_x = (p->Wo + 15) / 16;
+    *nbx = q->tiles_x * ((p->Ho + 7) / 8);
+    flope_host::fastdiv_magic((unsigned)PW, &q->pw_mg, &q->pw_sh);
+    *lds = patch;
+  } else {
+    *nbx = *splitk ? (p->M + 31) / 32 : (p->M + 127) / 128;
+    *lds = *splitk ? 3 * 2 * nt * 4 * 64 * 4 : 0;
+  }
   return true;
 }
 static bool yconv_wants_xcd_bands(const YConvP* p, bool splitk, int nbx, int nby, int mode) {
@@ -807,22 +1041,24 @@ extern "C" int flope_yconv_xcd_mode(int mode) { const int prev = g_xcd_mode; if 
 
 // nt = channel tiles of 16 per workgroup column (1, 2 or 4): rows of p->w / p->bias = ceil(Cout / (16 nt)) * 16 nt
 extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stream) {
-  bool splitk; int nbx, nby;
-  if (!yconv_geometry(p, nt, &splitk, &nbx, &nby)) return (int)hipErrorInvalidValue;
+  bool splitk; int nbx, nby, lds;
+  YConvP q;
+  if (!yconv_geometry(p, nt, &q, &splitk, &nbx, &nby, &lds)) return (int)hipErrorInvalidValue;
   const dim3 grid(nbx, nby);
-  YConvP q = *p;
   q.xcd = yconv_wants_xcd_bands(p, splitk, nbx, nby, g_xcd_mode) ? 1 : 0;
-  if (dtype == 0) yconv_go<bf16_t>(q, nt, splitk, grid, (hipStream_t)stream); else yconv_go<f16_t>(q, nt, splitk, grid, (hipStream_t)stream);
+  if (dtype == 0) yconv_go<bf16_t>(q, nt, splitk, grid, lds, (hipStream_t)stream); else yconv_go<f16_t>(q, nt, splitk, grid, lds, (hipStream_t)stream);
   return (int)hipGetLastError();
 }
 
 // ---- several independent ops in one grid (ymulti_kernel) ---------------------------------------------------------
 extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt) {
-  bool splitk; int nbx, nby;
-  if (m->n >= kYMultiMax || !yconv_geometry(p, nt, &splitk, &nbx, &nby)) return (int)hipErrorInvalidValue;
+  bool splitk; int nbx, nby, lds;
+  YConvP q;
+  if (m->n >= kYMultiMax || !yconv_geometry(p, nt, &q, &splitk, &nbx, &nby, &lds)) return (int)hipErrorInvalidValue;
   YMultiOp& o = m->op[m->n++];
   o.code = (nt == 1 ? 0 : nt == 2 ? 4 : 8) + (p->k == 3 ? 2 : 0) + (splitk ? 1 : 0);
-  o.nbx = nbx; o.start = m->total; o.nblocks = nbx * nby; o.u.c = *p;
+  o.nbx = nbx; o.start = m->total; o.nblocks = nbx * nby; o.u.c = q;
+  m->lds = std::max(m->lds, lds);
   o.u.c.xcd = yconv_wants_xcd_bands(p, splitk, nbx, nby, g_xcd_mode) ? 1 : 0;
   m->total += (o.nblocks + 7) / 8 * 8;
   return 0;
@@ -836,9 +1072,10 @@ extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p) {
   return 0;
 }
 
-extern "C" int flope_ymulti_launch(const YMultiP* m, int dtype, void* stream) {
-  if (m->n < 1 || m->n > kYMultiMax || m->total < 1) return (int)hipErrorInvalidValue;
-  YDISPATCH(dtype, ymulti_kernel, dim3(m->total), dim3(256), 0, (hipStream_t)stream, *m);
+// m: the host copy (grid, LDS size); m_dev: the same table in device memory, read by the kernel
+extern "C" int flope_ymulti_launch(const YMultiP* m, const YMultiP* m_dev, int dtype, void* stream) {
+  if (!m_dev || m->n < 1 || m->n > kYMultiMax || m->total < 1) return (int)hipErrorInvalidValue;
+  YDISPATCH(dtype, ymulti_kernel, dim3(m->total), dim3(256), m->lds, (hipStream_t)stream, m_dev);
   return (int)hipGetLastError();
 }
 
@@ -849,8 +1086,16 @@ extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream) {
   return (int)hipGetLastError();
 }
 
+constexpr size_t kYSppfLdsMax = 144 * 1024;
+static int g_pool_lds = 1;                                   // 0: the ring kernel for every map (A/B, parity of the two)
+extern "C" int flope_ypool_lds_mode(int mode) { const int prev = g_pool_lds; if (mode == 0 || mode == 1) g_pool_lds = mode; return prev; }
 extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream) {
-  if (p->C % 8) return (int)hipErrorInvalidValue;
+  if (p->C % 8 || p->n < 1 || p->n > 3) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)2 * p->H * p->W * 16;
+  if (g_pool_lds && lds <= kYSppfLdsMax) {
+    YDISPATCH(dtype, ysppf_lds_kernel, dim3(p->C / 8), dim3(256), lds, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+  }
   const int total = p->H * p->W * (p->C / 8);
   YDISPATCH(dtype, ypool_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
@@ -868,6 +1113,14 @@ extern "C" int flope_yattn_init() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define YLDS(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYTileLdsMax)
+#define YLDS_T(T) YLDS((yconv_kernel<T, 1, false, false>)); YLDS((yconv_kernel<T, 1, true, false>)); YLDS((yconv_kernel<T, 2, false, false>)); \
+  YLDS((yconv_kernel<T, 2, true, false>)); YLDS((yconv_kernel<T, 4, false, false>)); YLDS((yconv_kernel<T, 4, true, false>)); YLDS(ymulti_kernel<T>)
+  YLDS_T(bf16_t); YLDS_T(f16_t);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ysppf_lds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kYSppfLdsMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ysppf_lds_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kYSppfLdsMax);
+#undef YLDS_T
+#undef YLDS
   return (int)e;
 }
 

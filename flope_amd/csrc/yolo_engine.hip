@@ -25,8 +25,11 @@ extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stre
 extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream);
 extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt);
 extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p);
-extern "C" int flope_ymulti_launch(const YMultiP* m, int dtype, void* stream);
+extern "C" int flope_ymulti_launch(const YMultiP* m, const YMultiP* m_dev, int dtype, void* stream);
 extern "C" int flope_yconv_xcd_mode(int mode);
+extern "C" int flope_yconv_tile_mode(int mode);
+extern "C" int flope_yconv_splitk_max_m(int m);
+extern "C" int flope_ypool_lds_mode(int mode);
 extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream);
 extern "C" int flope_yup_launch(const YUpP* p, void* stream);
 extern "C" int flope_yattn_init();
@@ -60,7 +63,7 @@ struct Op {
 };
 
 // One launch of the schedule: a single op, or up to kYMultiMax independent conv / depthwise ops of one level in one grid.
-struct Launch { int op = -1; YMultiP multi; std::vector<int> members; };
+struct Launch { int op = -1; YMultiP multi; YMultiP* multi_dev = nullptr; std::vector<int> members; };
 
 struct Tap { int is_f32 = 0; const void* ptr = nullptr; int H = 0, W = 0, C = 0, ld = 0; };
 
@@ -307,10 +310,11 @@ struct Builder {
     push(op);
   }
 
-  void pool(const View& in, const View& out) {
-    Op op; op.kind = Op::POOL; op.name = "maxpool5";
+  // n cascaded MaxPool2d(5, 1, 2) of `in`; result i lands in channels [i C, (i + 1) C) of `out` (out.C = n * in.C)
+  void pool(const View& in, const View& out, int n) {
+    Op op; op.kind = Op::POOL; op.name = "maxpool5 x" + std::to_string(n);
     op.pool.in = vptr(in); op.pool.H = vH(in); op.pool.W = vW(in); op.pool.C = in.C; op.pool.ldi = vld(in);
-    op.pool.out = vptr(out); op.pool.ldo = vld(out);
+    op.pool.out = vptr(out); op.pool.ldo = vld(out); op.pool.n = n;
     op.reads.push_back(rng(in)); op.writes.push_back(rng(out));
     push(op);
   }
@@ -359,7 +363,7 @@ struct Builder {
   void sppf(const std::string& p, const View& in, const View& out) {
     const int c_ = cout(p + ".cv1"), y = tensor(vH(in), vW(in), 4 * c_);
     conv(p + ".cv1", in, slice(y, 0, c_), 1, 1);
-    for (int i = 0; i < 3; ++i) pool(slice(y, i * c_, c_), slice(y, (i + 1) * c_, c_));
+    pool(slice(y, 0, c_), slice(y, c_, 3 * c_), 3);          // y1 = m(x), y2 = m(y1), y3 = m(y2) in one sweep
     conv(p + ".cv2", full(y), out, 1, 1);
   }
   void c2psa(const std::string& p, const View& in, const View& out) {
@@ -402,7 +406,7 @@ int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
 }
 
 int launch_one(flope_yolo* e, const Launch& L, hipStream_t st) {
-  return L.op >= 0 ? launch_op(e, e->ops[L.op], st) : flope_ymulti_launch(&L.multi, e->dtype, st);
+  return L.op >= 0 ? launch_op(e, e->ops[L.op], st) : flope_ymulti_launch(&L.multi, L.multi_dev, e->dtype, st);
 }
 
 std::string launch_name(const flope_yolo* e, const Launch& L) {
@@ -459,6 +463,10 @@ int build_schedules(flope_yolo* e) {
         if (s) return yfail(e, FLOPE_EINVAL, "schedule: cannot batch " + op.name);
         L.members.push_back(batchable[at + k]);
       }
+      if (hipMalloc((void**)&L.multi_dev, sizeof(YMultiP)) != hipSuccess ||
+          hipMemcpy(L.multi_dev, &L.multi, sizeof(YMultiP), hipMemcpyHostToDevice) != hipSuccess)
+        return yfail(e, FLOPE_EHIP, "schedule: parameter table upload failed");
+      e->owned.push_back(L.multi_dev);
       e->sched[1].push_back(L);
     }
   }
@@ -746,11 +754,12 @@ extern "C" int flope_yolo_read_tensor(flope_yolo_handle e, const char* name, flo
 extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int value) {
   if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
-  if (!strcmp(name, "xcd")) {                      // process-wide A/B knob; the batched schedule bakes it in at load time
-    const int prev = flope_yconv_xcd_mode(value);
+  if (!strcmp(name, "xcd") || !strcmp(name, "tile") || !strcmp(name, "splitk_max_m")) {   // process-wide A/B knobs; the batched schedule bakes them in
+    const int prev = !strcmp(name, "xcd") ? flope_yconv_xcd_mode(value) : !strcmp(name, "tile") ? flope_yconv_tile_mode(value) : flope_yconv_splitk_max_m(value);
     if (e->loaded) { if (int rc = build_schedules(e)) return rc; if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; } }
     return prev;
   }
+  if (!strcmp(name, "pool_lds")) return flope_ypool_lds_mode(value);
   if (!strcmp(name, "batch")) { const int prev = e->opt_batch; e->opt_batch = value != 0; return prev; }
   if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);

@@ -95,6 +95,31 @@ def test_batched_launches_and_graph_replay_do_not_change_a_bit(ysd):
     y.close()
 
 
+def test_lds_tile_path_equals_the_global_fragment_path(ysd):
+    """Large maps stage an 8 x 16 output tile's input patch in LDS (default); option tile=0 reads the same fragments
+    straight from global memory.  Same MFMA sequence per output pixel: every graph output and the head rows identical."""
+    from flope_amd.yolo_weights import synthetic_frame
+    for (H, W, imgsz) in ((1080, 1920, 1280), (360, 640, 640), (250, 333, 320)):
+        img = synthetic_frame(11, H, W)
+        y = _engine(ysd, H, W, imgsz)
+        outs = []
+        for tile in (1, 0):
+            y.set_option("tile", tile)
+            y.forward(img)
+            outs.append([y.read_tensor(k).cpu().numpy() for k in ("0", "1", "2", "3", "4", "13", "16", "19", "22", "proto", "box0", "cls0", "coef0", "box2")])
+        y.set_option("tile", 1)
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        # SPPF's three cascaded 5x5 max-pools: the LDS kernel (row / column passes) against the 13 x 13 ring sweep
+        y.set_option("pool_lds", 0)
+        y.forward(img)
+        ring = y.read_tensor("9").cpu().numpy()
+        y.set_option("pool_lds", 1)
+        y.forward(img)
+        assert np.array_equal(ring, y.read_tensor("9").cpu().numpy())
+        y.close()
+
+
 def _head_rows(y):
     """the device's own float32 head rows as the oracle's `o` dict"""
     o = {}

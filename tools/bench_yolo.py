@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1, help="0: one launch per op in program order")
     ap.add_argument("--xcd", type=int, default=-1, help="XCD band remap of conv workgroups: 0 never, 1 3x3 convs (default), 2 also 1x1")
+    ap.add_argument("--opt", action="append", default=[], help="name=value engine option (repeatable)")
     ap.add_argument("--per-launch", action="store_true", help="print the per-launch time table (HIP events) and exit")
     args = ap.parse_args()
     from flope_amd.yolo import YoloSeg
@@ -30,6 +31,9 @@ def main():
     y.set_option("batch", args.batch)
     if args.xcd >= 0:
         y.set_option("xcd", args.xcd)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        y.set_option(k, int(v))
     frame = torch.from_numpy(synthetic_frame(0)).cuda()
     if args.per_launch:
         print(y.profile(frame, 20))
