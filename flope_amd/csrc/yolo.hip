@@ -595,17 +595,28 @@ __global__ __launch_bounds__(256) void yattn_mfma_kernel(const YAttnP p) {
   const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const char* base = (const char*)p.qkv + (size_t)h * 256;
   const size_t ldB = (size_t)p.ld * 2;
-  for (int i = tid; i < NB * 32 * 8; i += 256) {
-    const int j = i >> 3, c = i & 7;
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (j < p.N) v = *(const u32x4*)(base + (size_t)j * ldB + 128 + c * 16);
-    const int jj = j & 31;
-    const int pos = jj < 16 ? 8 * (jj >> 2) + (jj & 3) : 8 * ((jj - 16) >> 2) + 4 + (jj & 3);
-    char* d = vt + (size_t)(8 * c) * rowB + ((j & ~31) + pos) * 2;
+  // V rows -> V^T in LDS, eight 16-byte loads in flight per thread (one at a time, each of the 29 rounds at 920 tokens
+  // waited for its own L2 round trip: half of the kernel's time)
+  for (int i0 = tid; i0 < NB * 32 * 8; i0 += 8 * 256) {
+    u32x4 v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      *(unsigned short*)(d + (size_t)(2 * e) * rowB) = (unsigned short)(v[e] & 0xffffu);
-      *(unsigned short*)(d + (size_t)(2 * e + 1) * rowB) = (unsigned short)(v[e] >> 16);
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256, j = i >> 3, c = i & 7;
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (j < p.N) v[u] = *(const u32x4*)(base + (size_t)j * ldB + 128 + c * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256, j = i >> 3, c = i & 7;
+      if (i >= NB * 32 * 8) break;
+      const int jj = j & 31;
+      const int pos = jj < 16 ? 8 * (jj >> 2) + (jj & 3) : 8 * ((jj - 16) >> 2) + 4 + (jj & 3);
+      char* d = vt + (size_t)(8 * c) * rowB + ((j & ~31) + pos) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *(unsigned short*)(d + (size_t)(2 * e) * rowB) = (unsigned short)(v[u][e] & 0xffffu);
+        *(unsigned short*)(d + (size_t)(2 * e + 1) * rowB) = (unsigned short)(v[u][e] >> 16);
+      }
     }
   }
   __syncthreads();
