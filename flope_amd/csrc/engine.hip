@@ -492,7 +492,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
-  else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value != 0; return prev; }
+  else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -658,12 +658,20 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
                                           : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
-      // split-K for small batches: with fewer tiles than half the CUs a tile's serial K loop (up to 72 double steps)
-      // is the layer's latency; give every tile ksplit workgroups, each a share of the input channels
+      // split-K for small batches: with fewer tiles than half the CUs a tile's serial K loop (up to 72 double steps) is the
+      // layer's latency; give every tile ksplit workgroups, each a share of the input channels.  A split pays its fp32
+      // partial sums (128 KB per workgroup, written and read back) and a finalize launch, so the factor is chosen by a small
+      // cost model fitted to B = 16 / 31 @ 512^2 (layer 3, 128 tiles, x2: 40 vs 37 us -- a loss; layer 4, 124 tiles, x2: a win;
+      // layer 4, 64 tiles, x4: 37 vs 55 us): gain = T (1 - 1/s) - (5 us + 0.066 us * tiles * s), T = 0.75 us per double step.
       int ksp = 1;
       if (e->opt_ksplit && c.stag == 1 && e->cur_slices == 1 && !e->opt_persist && p.total_tiles * 2 <= e->num_cus) {
         const int bodies = c.cin / 64;
-        while (ksp * 2 <= bodies && bodies % (ksp * 2) == 0 && p.total_tiles * ksp * 2 <= e->num_cus) ksp *= 2;
+        const double T = 0.75 * 9.0 * bodies;
+        double best = 0.0;
+        for (int sp = 2; sp <= bodies && bodies % sp == 0 && p.total_tiles * sp <= e->num_cus; sp *= 2) {
+          const double gain = e->opt_ksplit == 2 ? sp : T * (1.0 - 1.0 / sp) - (5.0 + 0.066 * p.total_tiles * sp);
+          if (gain > best) { best = gain; ksp = sp; }
+        }
       }
       ConvP pf;
       if (ksp > 1) {
