@@ -29,6 +29,10 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 16
 echo "bench done"
 python tools/bench_e2e.py yolo 4 16 31 > $OUT/e2e.txt 2>&1
 python tools/bench_yolo.py > $OUT/yolo_bench.json 2> $OUT/yolo_bench.err
+python tools/bench_yolo.py --batch 0 >> $OUT/yolo_bench.json 2>> $OUT/yolo_bench.err
+python tools/bench_yolo.py --per-launch 2> /dev/null > $OUT/yolo_per_launch.txt
+$ROOT/build/launch_floor > $OUT/launch_floor.txt 2>&1
+python tools/probe_pipeline.py 2>&1 | grep -v amdgpu.ids > $OUT/pipeline_phases.txt
 python tools/latency.py > $OUT/latency.txt 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_yolo -- python3 $ROOT/tools/bench_yolo.py --profile-iters 20 > $OUT/kt_yolo.log 2>&1
