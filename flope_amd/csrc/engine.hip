@@ -24,7 +24,7 @@ extern "C" int flope_stem_init();
 extern "C" int flope_stem_launch(const StemP* p, int dtype, size_t lds, void* stream);
 extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream);
 extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, int w, int C, int dtype, void* stream);
-extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* b1, float* hidden, int B, int K, int N, void* stream);
+extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* W1p, const float* b1, float* hidden, int B, int K, int N, void* stream);
 extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, const float* xyz, int nullify, float* Rt, void* stream);
 extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
@@ -87,10 +87,10 @@ struct flope_engine {
   std::vector<Conv> convs;
   int stage_buf[10];                 // FLOPE_STAGE_* (0..9) -> buffer index
   int final_buf = -1;
-  float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+  float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1;
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -475,7 +475,7 @@ extern "C" int flope_destroy(flope_handle e) {
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
   for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.bias_fused) hipFree(c.bias_fused); }
-  void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
+  void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
@@ -492,6 +492,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
+  else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
@@ -561,6 +562,7 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
   if ((rc = chk(w1, (size_t)e->bod * 512, "base.fc.0.weight")) || (rc = chk(b1, e->bod, "base.fc.0.bias")) ||
       (rc = chk(w2, (size_t)9 * e->bod, "fc_rot.weight")) || (rc = chk(b2, 9, "fc_rot.bias"))) return rc;
   if ((rc = upload(e, std::vector<float>(w1, w1 + (size_t)e->bod * 512), (void**)&e->W1)) != 0) return rc;
+  if (e->bod % 16 == 0 && (rc = upload(e, flope_host::pack_fc1(w1, e->bod, 512), (void**)&e->W1p)) != 0) return rc;
   if ((rc = upload(e, std::vector<float>(b1, b1 + e->bod), (void**)&e->b1)) != 0) return rc;
   if ((rc = upload(e, std::vector<float>(w2, w2 + (size_t)9 * e->bod), (void**)&e->W2)) != 0) return rc;
   if ((rc = upload(e, std::vector<float>(b2, b2 + 9), (void**)&e->b2)) != 0) return rc;
@@ -693,7 +695,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
   SMARK();
   K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
   SMARK();
-  K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->b1, hidden, batch, 512, e->bod, stream));
+  K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->opt_fc1_packed ? e->W1p : nullptr, e->b1, hidden, batch, 512, e->bod, stream));
   if (head) {
     SMARK();
     float* r9 = (r9_dev ? r9_dev : e->r9_scratch) + (size_t)start * 9;

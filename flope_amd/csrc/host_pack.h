@@ -165,4 +165,19 @@ inline std::vector<float> naive_layout(const std::vector<float>& wf, int cout, i
 }
 
 
+// fc.0 weights W1 [N][K] (N % 16 == 0, K % 32 == 0) in the A-fragment order of fc1_packed_kernel:
+// [n tile][K / 32][2][lane = g * 16 + r][4]  <-  W1[(tile * 16 + r) * K + kb * 32 + h * 16 + 4 g + s]
+inline std::vector<float> pack_fc1(const float* W1, int N, int K) {
+  std::vector<float> out((size_t)N * K);
+  const int KB = K / 32;
+  for (int t = 0; t < N / 16; ++t)
+    for (int kb = 0; kb < KB; ++kb)
+      for (int h = 0; h < 2; ++h)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s)
+            out[((((size_t)t * KB + kb) * 2 + h) * 64 + lane) * 4 + s] =
+                W1[(size_t)(t * 16 + (lane & 15)) * K + kb * 32 + h * 16 + 4 * (lane >> 4) + s];
+  return out;
+}
+
 }  // namespace flope_host

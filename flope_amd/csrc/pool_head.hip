@@ -184,6 +184,77 @@ __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ feat
   }
 }
 
+// The same arithmetic (same K order per output: bit-identical) with coalesced operands.  In fc1_kernel every wave-load puts
+// its 64 lanes on 16 rows = 64 different cache lines (weights 2 KB apart, feature rows too) and the L1's tag rate, not bytes,
+// sets its 19 us.  Here W1 is pre-packed in A-fragment order [n tile][K / 32][2][lane][4] (a wave-load = one contiguous KiB)
+// and the workgroup's 32 feature rows are staged once into LDS (row pitch K + 4 floats: conflict-free ds_read_b128).
+__global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict__ feat, const float* __restrict__ W1p,
+                                                         const float* __restrict__ b1, float* __restrict__ hidden,
+                                                         int B, int K, int N) {
+  extern __shared__ __attribute__((aligned(16))) float sfeat[];           // [32][K + 4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int ntile = blockIdx.x * 4 + wave;
+  const int n0 = ntile * 16;
+  const int img0 = blockIdx.y * 32;
+  const int KB = K >> 5, pitch = K + 4, k4 = K >> 2;
+  const f32x4* wp = (const f32x4*)W1p + ((size_t)min(ntile, N / 16 - 1) * KB * 2) * 64 + lane;
+  constexpr int WPD = 4;                                    // weight K blocks in flight (issued before the feature staging)
+  f32x4 wa[WPD][2];
+#pragma unroll
+  for (int d = 0; d < WPD; ++d) { const int kb = min(d, KB - 1); wa[d][0] = wp[(size_t)kb * 128]; wa[d][1] = wp[(size_t)kb * 128 + 64]; }
+  for (int i0 = tid; i0 < 32 * k4; i0 += 4 * 256) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * 256, 32 * k4 - 1), row = i / k4, c = i - row * k4;
+      v[u] = *(const f32x4*)(feat + (size_t)min(img0 + row, B - 1) * K + 4 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256, row = i / k4, c = i - row * k4;
+      if (i < 32 * k4) *(f32x4*)(sfeat + row * pitch + 4 * c) = v[u];
+    }
+  }
+  __syncthreads();
+  if (n0 >= N) return;
+  f32x4 acc[2][2];                                          // [image tile][K parity]: 4 independent chains
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+  const float* f0p = sfeat + r16 * pitch + 4 * g;
+  for (int kb0 = 0; kb0 < KB; kb0 += WPD) {
+#pragma unroll
+    for (int d = 0; d < WPD; ++d) {
+      const int kb = kb0 + d;
+      if (kb >= KB) break;
+      const f32x4 a0 = wa[d][0], a1 = wa[d][1];
+      const int nb = min(kb + WPD, KB - 1);
+      wa[d][0] = wp[(size_t)nb * 128]; wa[d][1] = wp[(size_t)nb * 128 + 64];
+      f32x4 f0[2], f1[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { f0[t] = *(const f32x4*)(f0p + t * 16 * pitch + kb * 32); f1[t] = *(const f32x4*)(f0p + t * 16 * pitch + kb * 32 + 16); }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], f0[t][s], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], f1[t][s], acc[t][1], 0, 0, 0);
+        }
+    }
+  }
+  const f32x4 bias = *(const f32x4*)(b1 + n0 + 4 * g);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int img = img0 + t * 16 + r16;
+    if (img < B) {
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = fmaxf(acc[t][0][q] + acc[t][1][q] + bias[q], 0.f);
+      *(f32x4*)(hidden + (size_t)img * N + n0 + 4 * g) = o;
+    }
+  }
+}
+
 // generic fallback when K % 16 != 0 or N % 16 != 0 (non-default backbone_out_dim)
 __global__ __launch_bounds__(256) void fc1_simple_kernel(const float* feat, const float* W1, const float* b1,
                                                          float* hidden, int B, int K, int N) {
@@ -195,10 +266,17 @@ __global__ __launch_bounds__(256) void fc1_simple_kernel(const float* feat, cons
   hidden[i] = fmaxf(s, 0.f);
 }
 
-extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* b1, float* hidden, int B, int K,
+// W1p: W1 in fragment order (host_pack.h pack_fc1) or NULL
+extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* W1p, const float* b1, float* hidden, int B, int K,
                                 int N, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (K % 32 == 0 && N % 16 == 0) {
+  const size_t lds = (size_t)32 * (K + 4) * sizeof(float);
+  if (W1p && K % 32 == 0 && N % 16 == 0 && lds <= 96 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)fc1_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; }
+    const dim3 grid((N / 16 + 3) / 4, (B + 31) / 32);
+    hipLaunchKernelGGL(fc1_packed_kernel, grid, dim3(256), lds, st, feat, W1p, b1, hidden, B, K, N);
+  } else if (K % 32 == 0 && N % 16 == 0) {
     const dim3 grid((N / 16 + 3) / 4, (B + 31) / 32);
     hipLaunchKernelGGL(fc1_kernel, grid, dim3(256), 0, st, feat, W1, b1, hidden, B, K, N);
   } else {

@@ -210,6 +210,21 @@ def test_split_k_small_batches(state_dict, H, W, B):
     e.close()
 
 
+@pytest.mark.parametrize("B", [1, 37, 256])
+def test_fc1_packed_weights_equal_the_row_major_kernel(state_dict, B):
+    """fc.0 on pre-packed (A-fragment order) weights with LDS-staged feature rows runs the same MFMA sequence per output as
+    the row-major kernel: `hidden` and the rotations are identical, also for batches that are not multiples of 32."""
+    torch.manual_seed(B)
+    x = torch.rand(B, 96, 96, 3).to(torch.float16).cuda()
+    e = _engine(state_dict, 96, 96, B, "f16")
+    r9a, Ra = e.forward(x)
+    ha = e.read_stage("hidden", B).clone()
+    assert e.set_option("fc1_packed", 0) == 1
+    r9b, Rb = e.forward(x)
+    assert torch.equal(ha, e.read_stage("hidden", B)) and torch.equal(r9a, r9b) and torch.equal(Ra, Rb)
+    e.close()
+
+
 @pytest.mark.parametrize("B", [131, 200, 255])
 def test_slice_split_is_invisible(state_dict, B):
     """The internal two-slice split (3/8 : 5/8 on multiples of 8 images, row-band grids proportional to the slice) must
