@@ -14,6 +14,7 @@
 #include "yolo.h"
 
 #include <math.h>
+#include <algorithm>
 #include <stdio.h>
 #include <string.h>
 
@@ -48,6 +49,7 @@ namespace {
 thread_local std::string g_yolo_error;
 constexpr double kYoloBnEps = 1e-3;            // ultralytics: BatchNorm2d(eps=0.001)
 constexpr int kRegMax = 16, kNm = 32, kMaxDet = 300;
+constexpr size_t kGraphCache = 8;              // one captured sequence per (frame, thresholds, output buffers) tuple in use
 
 struct View { int t = -1, off = 0, C = 0; };   // channel slice [off, off + C) of tensor t
 struct Tensor { void* ptr = nullptr; int H = 0, W = 0, C = 0; };
@@ -94,8 +96,7 @@ struct flope_yolo {
   // into ONE grid (ymulti_kernel): option "batch", default on.
   int opt_batch = 1;
   int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
-  hipGraphExec_t graph_exec = nullptr;
-  GraphKey graph_key = {};
+  std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // captured detect sequences, most recently used last (<= kGraphCache)
   double flops = 0.0;
   std::string err;
 };
@@ -506,7 +507,7 @@ extern "C" int flope_yolo_destroy(flope_yolo_handle e) {
   if (!e) return FLOPE_OK;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
-  if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+  for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
   for (Tensor& t : e->tensors) if (t.ptr) hipFree(t.ptr);
   for (void* p : e->owned) if (p) hipFree(p);
   delete e;
@@ -717,8 +718,14 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
   GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch, e->opt_generic_attn};
-  if (!e->graph_exec || memcmp(&key, &e->graph_key, sizeof key) != 0) {
-    if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+  hipGraphExec_t exec = nullptr;
+  for (size_t i = 0; i < e->graphs.size(); ++i)
+    if (memcmp(&key, &e->graphs[i].first, sizeof key) == 0) {
+      exec = e->graphs[i].second;
+      if (i + 1 != e->graphs.size()) std::rotate(e->graphs.begin() + i, e->graphs.begin() + i + 1, e->graphs.end());
+      break;
+    }
+  if (!exec) {
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
       (void)hipGetLastError();                              // e.g. the legacy null stream cannot be captured: run eagerly
@@ -728,12 +735,13 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
     const hipError_t ec = hipStreamEndCapture(st, &g);
     if (rc) { if (g) hipGraphDestroy(g); return rc; }
     if (ec != hipSuccess || !g) return yfail(e, FLOPE_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
-    const hipError_t ei = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
+    const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
-    if (ei != hipSuccess) { e->graph_exec = nullptr; return yfail(e, FLOPE_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
-    e->graph_key = key;
+    if (ei != hipSuccess) return yfail(e, FLOPE_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+    if (e->graphs.size() >= kGraphCache) { hipGraphExecDestroy(e->graphs.front().second); e->graphs.erase(e->graphs.begin()); }
+    e->graphs.emplace_back(key, exec);
   }
-  Y_TRY(e, hipGraphLaunch(e->graph_exec, st));
+  Y_TRY(e, hipGraphLaunch(exec, st));
   return FLOPE_OK;
 }
 
@@ -756,7 +764,11 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
   if (!strcmp(name, "xcd") || !strcmp(name, "tile") || !strcmp(name, "splitk_max_m")) {   // process-wide A/B knobs; the batched schedule bakes them in
     const int prev = !strcmp(name, "xcd") ? flope_yconv_xcd_mode(value) : !strcmp(name, "tile") ? flope_yconv_tile_mode(value) : flope_yconv_splitk_max_m(value);
-    if (e->loaded) { if (int rc = build_schedules(e)) return rc; if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; } }
+    if (e->loaded) {
+      if (int rc = build_schedules(e)) return rc;
+      for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
+      e->graphs.clear();
+    }
     return prev;
   }
   if (!strcmp(name, "pool_lds")) return flope_ypool_lds_mode(value);

@@ -120,7 +120,9 @@ class FastPosePredictor:
             from flope_amd.yolo import YoloSeg, load_yolo_checkpoint
             sd, ck_imgsz = load_yolo_checkpoint(str(yolo_path))
             # ultralytics predicts at the size the checkpoint was trained with (the reference's is `yolo11nseg_1280.pt`, :177)
-            self.yolo = YoloSeg(int(self.height), int(self.width), int(imgsz or ck_imgsz or 1280), yolo_dtype, device=device)
+            self._yolo_args = (sd, int(imgsz or ck_imgsz or 1280), yolo_dtype)
+            self._yolo_b = None                # second detector instance of the pipelined loop, built on first use
+            self.yolo = YoloSeg(int(self.height), int(self.width), self._yolo_args[1], yolo_dtype, device=device)
             self.yolo.load_state_dict(sd)
             self._detector = self.yolo.get_bbox_mask
             print(f"YOLO loaded: {Path(str(yolo_path)).name}")
@@ -144,23 +146,33 @@ class FastPosePredictor:
         return poses_from_detections(self.posenet, rgb, depth, bb, mask, self.K, depth_div=1000.0,
                                      device=self.device)
 
-    def iter_flower_poses(self, frames):
-        """`get_flower_poses` over a stream of (rgb, depth) frames, software-pipelined three deep.  While the host reads the
-        boxes of frame t - 1 and enqueues its crops -> PoseResNet -> Procrustes on one HIP stream, the detector of frame t
-        is already queued on another (the detector is a chain of short, narrow launches; the pose network fills what it leaves
-        idle: 0.88 + 0.79 ms alone, 1.29 ms side by side), and the uploads of frame t + 1 go through a third.  Yields exactly
-        what get_flower_poses returns, frame by frame, in order, two frames late.  The reference loop
-        (scripts/live_pose.py:31-41) is sequential; this is the same computation with three frames in flight."""
+    def iter_flower_poses(self, frames, detectors: int = 2):
+        """`get_flower_poses` over a stream of (rgb, depth) frames, software-pipelined.  The detector is a chain of ~75 short,
+        narrow launches that leaves most of the GPU idle, so `detectors` (1 or 2) instances of it work on consecutive frames
+        on their own HIP streams (replaying captured hipGraphs: one host call per frame) while crops -> PoseResNet ->
+        Procrustes of an earlier frame run on another stream and the uploads of the next frame on a third; the host only ever
+        waits for the oldest detector.  Yields exactly what get_flower_poses returns, frame by frame, in order,
+        `detectors + 1` frames late.  The reference loop (scripts/live_pose.py:31-41) is sequential; this is the same
+        computation with several frames in flight."""
         if self.yolo is None:
             for rgb, depth in frames:
                 yield self.get_flower_poses(rgb, depth)
             return
         dev = torch.device(self.device)
-        s_io, s_det, s_pose = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        nd = 2 if detectors >= 2 else 1
+        if nd == 2 and self._yolo_b is None:
+            from flope_amd.yolo import YoloSeg
+            sd, imgsz, dt = self._yolo_args
+            self._yolo_b = YoloSeg(self.yolo.frame_h, self.yolo.frame_w, imgsz, dt, device=self.device)
+            self._yolo_b.load_state_dict(sd)
+        dets = [self.yolo, self._yolo_b][:nd]
+        s_io, s_pose = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        s_det = [torch.cuda.Stream(dev) for _ in range(nd)]
         H, W = self.yolo.frame_h, self.yolo.frame_w
-        NS = 3
+        NS = 2 * (nd + 1)                               # frames in flight: nd detecting, one in the pose stage, one being uploaded
         slots = [dict(frame=torch.empty((H, W, 3), dtype=torch.uint8, device=dev), out=self.yolo.new_outputs(), depth=None,
                       ready=None, pose_done=None, shape=None) for _ in range(NS)]
+        prev_graph = [d.set_option("graph", 1) for d in dets]
 
         def stage_detect(t, rgb, depth):
             sl = slots[t % NS]
@@ -176,11 +188,12 @@ class FastPosePredictor:
                 up = torch.cuda.Event()
                 up.record(s_io)
             sl["shape"] = rgb.shape
-            with torch.cuda.stream(s_det):
-                s_det.wait_event(up)
-                self.yolo.detect_device(sl["frame"], out=sl["out"], in_place=True)
+            st = s_det[t % nd]
+            with torch.cuda.stream(st):
+                st.wait_event(up)
+                dets[t % nd].detect_device(sl["frame"], out=sl["out"], in_place=True)
                 sl["ready"] = torch.cuda.Event()
-                sl["ready"].record(s_det)
+                sl["ready"].record(st)
 
         def read_boxes(t):
             sl = slots[t % NS]
@@ -203,20 +216,25 @@ class FastPosePredictor:
             with torch.cuda.stream(s_pose):
                 return finish_poses(packed)
 
-        detecting, posing = [], []                     # frame indices in flight per stage (oldest first)
-        for t, (rgb, depth) in enumerate(frames):
-            stage_detect(t, rgb, depth)
-            detecting.append(t)
-            if len(detecting) == 2:                     # frame t - 1: its detector ran while this frame was uploaded and queued
-                u = detecting.pop(0)
+        try:
+            detecting, posing = [], []                 # frame indices in flight per stage (oldest first)
+            for t, (rgb, depth) in enumerate(frames):
+                stage_detect(t, rgb, depth)
+                detecting.append(t)
+                if len(detecting) > nd:                 # the oldest detector ran while nd newer frames were uploaded and queued
+                    u = detecting.pop(0)
+                    bb = read_boxes(u)
+                    if posing:
+                        yield finish(posing.pop(0))     # before new pose work queues up behind it
+                    posing.append(stage_pose(u, bb))
+            for u in detecting:
                 bb = read_boxes(u)
                 if posing:
-                    yield finish(posing.pop(0))         # frame t - 2, before new pose work queues up behind it
+                    yield finish(posing.pop(0))
                 posing.append(stage_pose(u, bb))
-        for u in detecting:
-            bb = read_boxes(u)
-            if posing:
-                yield finish(posing.pop(0))
-            posing.append(stage_pose(u, bb))
-        for packed in posing:
-            yield finish(packed)
+            for packed in posing:
+                yield finish(packed)
+        finally:
+            torch.cuda.synchronize(dev)
+            for d, g in zip(dets, prev_graph):
+                d.set_option("graph", g)

@@ -273,9 +273,9 @@ def test_other_checkpoints_scale_s_and_several_classes(widths, nc, seed, H, W, i
 
 
 def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path):
-    """FastPosePredictor.iter_flower_poses (three frames in flight: uploads, detector and pose network on three streams,
-    per-slot frame / mask / box buffers) returns, frame by frame, exactly what get_flower_poses returns -- for streams
-    shorter than, equal to and longer than the pipeline depth."""
+    """FastPosePredictor.iter_flower_poses (several frames in flight: uploads, one or two detector instances replaying
+    captured hipGraphs, and the pose network on their own streams, per-slot frame / mask / box buffers) returns, frame by
+    frame, exactly what get_flower_poses returns -- for streams shorter than, equal to and longer than the pipeline depth."""
     import yaml
     from flope_amd.harness import live_pose_loop
     from flope_amd.yolo_weights import synthetic_frame
@@ -296,13 +296,14 @@ def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path
         frames.append((img, depth))
     seq = live_pose_loop(pred, frames)
     assert any(r is not None for r in seq) and seq[2] is None
-    for n in (8, 1, 2, 3, 0):
-        pip = live_pose_loop(pred, frames[:n], pipelined=True)
+    for n, nd in ((8, 2), (8, 1), (1, 2), (2, 2), (3, 2), (4, 2), (0, 2), (3, 1)):
+        pip = list(pred.iter_flower_poses(frames[:n], detectors=nd))
         assert len(pip) == n
         for a, b in zip(seq, pip):
             assert (a is None) == (b is None)
             if a is not None:
                 assert np.array_equal(a, b)
+    assert len(live_pose_loop(pred, frames[:5], pipelined=True)) == 5
 
 
 def test_yolo_error_paths(ysd):

@@ -53,14 +53,16 @@ def main_yolo(tmp, ckpt, intr):
     dd = (time.perf_counter() - t0) / it
     print(f"[e2e+yolo] 1080p frame -> {bb.shape[0]} detections -> {0 if Rt is None else Rt.shape[0]} poses (512x512 crops): "
           f"{dt*1e3:.2f} ms/frame, {1/dt:.1f} frames/s; get_bbox_mask alone (numpy in, numpy out) {dd*1e3:.2f} ms", flush=True)
-    frames = [(rgb, depth)] * 60
-    list(pred.iter_flower_poses(frames[:5]))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = list(pred.iter_flower_poses(frames))
-    dp = (time.perf_counter() - t0) / len(frames)
-    print(f"[e2e+yolo, pipelined] uploads of frame t+1, detector of frame t, pose network of frame t-1 on three streams: "
-          f"{dp*1e3:.2f} ms/frame, {1/dp:.1f} frames/s, {sum(0 if o is None else o.shape[0] for o in outs)/len(frames)/dp:.0f} poses/s", flush=True)
+    frames = [(rgb, depth)] * 120
+    for nd in (1, 2):
+        list(pred.iter_flower_poses(frames[:12], detectors=nd))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = list(pred.iter_flower_poses(frames, detectors=nd))
+        dp = (time.perf_counter() - t0) / len(frames)
+        print(f"[e2e+yolo, pipelined, {nd} detector instance{'s' if nd > 1 else ''}] uploads, detector(s) and pose network of consecutive "
+              f"frames on their own streams: {dp*1e3:.2f} ms/frame, {1/dp:.1f} frames/s, "
+              f"{sum(0 if o is None else o.shape[0] for o in outs)/len(frames)/dp:.0f} poses/s", flush=True)
 
 
 def main():
