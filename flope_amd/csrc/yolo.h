@@ -39,14 +39,19 @@ struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU
   int blk, blk_stride, blk_off;              // blk != 0: input channel of output channel c = (c / blk) * blk_stride + blk_off + c % blk
 };
 
+// Bottleneck = cv2(cv1(x)) (+ x): two 3x3 stride-1 Conv+BN+SiLU of <= 64 channels each, fused through LDS (ybneck_body).
+// c1 / c2 are the launch parameters of the two convs exactly as the unfused path would use them (c1.out is never written).
+struct YBneckP { YConvP c1, c2; int tiles_x, pad_; };
+
 // ymulti_kernel: up to kYMultiMax independent conv / depthwise launches sharing one grid
 constexpr int kYMultiMax = 8;
 struct YMultiOp {
-  int code;                                  // 0..11: conv, (NT index 0/1/2) * 4 + (3x3 ? 2 : 0) + (split-K ? 1 : 0); 12: depthwise
+  int code;                                  // 0..11: conv, (NT index 0/1/2) * 4 + (3x3 ? 2 : 0) + (split-K ? 1 : 0); 12: depthwise;
+                                             // 16 + (NT1 index) * 4 + (NT2 index): fused Bottleneck
   int nbx;                                   // conv: workgroups along pixels (local block b -> (b % nbx, b / nbx))
   int start;                                 // first workgroup of this op in the grid (a multiple of 8)
   int nblocks;                               // its workgroups; the grid pads every op to a multiple of 8
-  union U { YConvP c; YDwP d; } u;
+  union U { YConvP c; YDwP d; YBneckP b; } u;
 };
 struct YMultiP { int n, total, lds, pad_; YMultiOp op[kYMultiMax]; };
 

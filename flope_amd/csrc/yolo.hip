@@ -312,6 +312,164 @@ __device__ __forceinline__ void yconv_tile_body(const YConvP& p, const int bx, c
   yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 K loop with the B fragments taken from an LDS image [pixel][channel] (pixel pitch `pitch` bytes, PW pixels per
+// row): lane pixel offsets poff[pt] (in pixels, tap (0,0)); A fragments from global memory, PD steps ahead, wf preloaded.
+template <typename T, int NT, int MTW>
+__device__ __forceinline__ void ylds_kloop3(const char* const wrow, const int ksteps, const int cg, const unsigned cg_mg, const unsigned cg_sh,
+                                            const char* const lds, const int pitch, const int PW, const int (&poff)[MTW],
+                                            typename Elem<T>::frag (&wf)[4][NT], f32x4 (&acc)[MTW][NT]) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int PD = 4;
+  const int g = (threadIdx.x & 63) >> 4;
+  const int klast = ksteps - 1;
+  auto xload = [&](int ks, frag (&xf)[MTW]) {
+    const int kg = ks * 4 + g;
+    const int tap = fastdiv(kg, cg_mg, cg_sh), c8 = kg - tap * cg, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    const bool tapok = tap < 9;
+    const int off = tapok ? (ky * PW + kx) * pitch + c8 * 16 : 0;
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt) {
+      frag f = *(const frag*)(lds + off + poff[pt] * pitch);
+      if (!tapok) f = frag{};
+      xf[pt] = f;
+    }
+  };
+  frag xa[MTW], xb[MTW];
+  xload(0, xa);
+  for (int ks = 0; ks < ksteps; ks += PD) {
+#pragma unroll
+    for (int s_ = 0; s_ < PD; ++s_) {
+      frag (&cur)[MTW] = (s_ & 1) ? xb : xa;
+      frag (&nxt)[MTW] = (s_ & 1) ? xa : xb;
+      if (ks + s_ < ksteps) {
+        xload(min(ks + s_ + 1, klast), nxt);
+#pragma unroll
+        for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[s_][ct], cur[pt], acc[pt][ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) wf[s_][ct] = *(const frag*)(wrow + (size_t)(min(ks + s_ + PD, klast) * NT + ct) * 1024);
+    }
+  }
+}
+
+// Bottleneck (ultralytics nn/modules/block.py): out = cv2(cv1(x)) (+ x), both 3x3 stride 1 with <= 64 output channels.  One
+// workgroup = an 8 x 16 output tile: the 12 x 20 input patch goes to LDS, cv1 is evaluated on the 10 x 18 pixels cv2 needs
+// (pixels outside the map are cv2's zero padding, not cv1 outputs), its SiLU output is parked in LDS as 16-bit NHWC and cv2
+// reads its taps from there -- one launch and no round trip of the intermediate map through memory.  Same MFMA sequence per
+// output as the two separate launches whenever those do not split K (the split-K path adds its partial sums in another order).
+template <typename T, int NT1, int NT2>
+__device__ __forceinline__ void ybneck_body(const YBneckP& p, const int bx, char* const lds) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int PD = 4, PW1 = 20, PH1 = 12, PW2 = 18, NQ = 10 * 18, MT1 = 3;
+  const YConvP& c1 = p.c1;
+  const YConvP& c2 = p.c2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;
+  const int oy0 = ty * 8, ox0 = tx * 16;
+  const int pitch1 = c1.Cin * 2 + 16, pitch2 = c2.Cin * 2 + 16;
+  char* const mid = lds + PH1 * PW1 * pitch1;
+  const char* const wrow1 = (const char*)c1.w + lane * 16;
+  const char* const wrow2 = (const char*)c2.w + lane * 16;
+  frag wf1[PD][NT1];
+#pragma unroll
+  for (int s_ = 0; s_ < PD; ++s_)
+#pragma unroll
+    for (int ct = 0; ct < NT1; ++ct) wf1[s_][ct] = *(const frag*)(wrow1 + (size_t)(min(s_, c1.ksteps - 1) * NT1 + ct) * 1024);
+  {
+    const int total = PH1 * PW1 * c1.cg;
+    const char* const in = (const char*)c1.in;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+      u32x4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 256, ic = min(i, total - 1);
+        const int pp = fastdiv(ic, c1.cg_mg, c1.cg_sh), c8 = ic - pp * c1.cg;
+        const int py = pp / PW1, px = pp - py * PW1;
+        const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+        const bool ok = (unsigned)iy < (unsigned)c1.Hi && (unsigned)ix < (unsigned)c1.Wi;
+        v[j] = ok ? *(const u32x4*)(in + ((size_t)(iy * c1.Wi + ix) * c1.ldi + c8 * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+        dst[j] = i < total ? pp * pitch1 + c8 * 16 : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (dst[j] >= 0) *(u32x4*)(lds + dst[j]) = v[j];
+    }
+  }
+  __syncthreads();
+  // ---- cv1 on the 10 x 18 intermediate pixels: wave w owns pixel tiles w, w + 4, w + 8 (flat index q, row-major 18 wide)
+  int q[MT1], poff1[MT1];
+#pragma unroll
+  for (int j = 0; j < MT1; ++j) {
+    q[j] = (wave + 4 * j) * 16 + c16;
+    const int qq = min(q[j], NQ - 1), qy = qq / PW2, qx = qq - qy * PW2;
+    poff1[j] = qy * PW1 + qx;
+  }
+  f32x4 acc1[MT1][NT1];
+#pragma unroll
+  for (int ct = 0; ct < NT1; ++ct) {
+    const f32x4 b = *(const f32x4*)(c1.bias + ct * 16 + g * 4);
+#pragma unroll
+    for (int j = 0; j < MT1; ++j) acc1[j][ct] = b;
+  }
+  ylds_kloop3<T, NT1, MT1>(wrow1, c1.ksteps, c1.cg, c1.cg_mg, c1.cg_sh, lds, pitch1, PW1, poff1, wf1, acc1);
+  frag wf2[PD][NT2];                                        // cv2's first weights travel while cv1's epilogue runs
+#pragma unroll
+  for (int s_ = 0; s_ < PD; ++s_)
+#pragma unroll
+    for (int ct = 0; ct < NT2; ++ct) wf2[s_][ct] = *(const frag*)(wrow2 + (size_t)(min(s_, c2.ksteps - 1) * NT2 + ct) * 1024);
+  {
+    const int ch0 = g * 4 * NT1;
+#pragma unroll
+    for (int j = 0; j < MT1; ++j) {
+      if (q[j] >= NQ) continue;
+      const int qy = q[j] / PW2, qx = q[j] - qy * PW2;
+      const int gy = oy0 - 1 + qy, gx = ox0 - 1 + qx;
+      const bool inside = (unsigned)gy < (unsigned)c1.Ho && (unsigned)gx < (unsigned)c1.Wo;
+      char* const d = mid + q[j] * pitch2 + ch0 * 2;
+#pragma unroll
+      for (int i = 0; i < 2 * NT1; ++i) {
+        const float a = acc1[j][i >> 1][(i & 1) * 2], b = acc1[j][i >> 1][(i & 1) * 2 + 1];
+        const unsigned w = inside ? pk_out16<T>(pack2<T>(c1.act ? silu(a) : a, c1.act ? silu(b) : b), false) : 0u;
+        if (ch0 + 2 * i < c2.Cin) *(unsigned*)(d + 4 * i) = w;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- cv2 on the 8 x 16 output pixels: wave w owns rows 2w, 2w + 1
+  int poff2[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) poff2[pt] = (wave * 2 + pt) * PW2 + c16;
+  f32x4 acc2[2][NT2];
+#pragma unroll
+  for (int ct = 0; ct < NT2; ++ct) {
+    const f32x4 b = *(const f32x4*)(c2.bias + ct * 16 + g * 4);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc2[pt][ct] = b;
+  }
+  ylds_kloop3<T, NT2, 2>(wrow2, c2.ksteps, c2.cg, c2.cg_mg, c2.cg_sh, mid, pitch2, PW2, poff2, wf2, acc2);
+  int mm[2];
+  bool pv[2];
+  const int ox = ox0 + c16;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int oy = oy0 + wave * 2 + pt;
+    pv[pt] = oy < c2.Ho && ox < c2.Wo;
+    mm[pt] = oy * c2.Wo + ox;
+  }
+  yconv_epilogue<T, NT2, 2>(c2, 0, g, mm, pv, acc2);
+}
+
+template <typename T, int NT1, int NT2>
+__global__ __launch_bounds__(256) void ybneck_kernel(const YBneckP p) {
+  extern __shared__ __attribute__((aligned(16))) char ylds[];
+  ybneck_body<T, NT1, NT2>(p, blockIdx.x, ylds);
+}
+
 // Workgroups are handed to the 8 XCDs round-robin (flat id mod 8), each XCD with its own 4 MiB L2.  On the large maps the
 // nine taps of a 3x3 conv re-read every input pixel nine times: with the natural order every XCD touches the whole map
 // (7.5 MB at 184 x 320 x 64) and the re-reads fall out of its L2.  Remapped, XCD x owns one contiguous run of tiles (an
@@ -392,6 +550,16 @@ __global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP* __restrict__
   int lb = b - o.start;                                   // op starts are multiples of 8: lb mod 8 is the XCD
   if (lb >= o.nblocks) return;
   if (o.code == 12) { ydw_body<T>(o.u.d, lb); return; }
+  if (o.code >= 16) {
+    switch (o.code - 16) {                               // (NT1 index) * 4 + (NT2 index)
+      case 0: ybneck_body<T, 1, 1>(o.u.b, lb, ylds); break;
+      case 1: ybneck_body<T, 1, 2>(o.u.b, lb, ylds); break;
+      case 5: ybneck_body<T, 2, 2>(o.u.b, lb, ylds); break;
+      case 6: ybneck_body<T, 2, 4>(o.u.b, lb, ylds); break;
+      default: ybneck_body<T, 4, 4>(o.u.b, lb, ylds); break;
+    }
+    return;
+  }
   if (o.u.c.xcd) lb = xcd_band(lb, o.nblocks);
   const int by = lb / o.nbx, bx = lb - by * o.nbx;
   if (o.u.c.tile) {
@@ -1089,6 +1257,55 @@ extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt) {
   return 0;
 }
 
+// ---- fused Bottleneck ------------------------------------------------------------------------------------------------
+// fusable: both 3x3 stride 1 on the same map, <= 64 output channels each, (NT1, NT2) one of the instantiated pairs, LDS fits
+static int ybneck_code(const YConvP* c1, int nt1, const YConvP* c2, int nt2, int* lds, int* tiles) {
+  if (c1->k != 3 || c2->k != 3 || c1->stride != 1 || c2->stride != 1 || c1->out_mode || c2->out_mode || c1->res) return -1;
+  if (c1->Ho != c2->Hi || c1->Wo != c2->Wi || c1->Cout > 16 * nt1 || c2->Cout > 16 * nt2 || c2->Cin != c1->Cout) return -1;
+  const int i1 = nt1 == 1 ? 0 : nt1 == 2 ? 1 : 2, i2 = nt2 == 1 ? 0 : nt2 == 2 ? 1 : 2, code = i1 * 4 + i2;
+  if (code != 0 && code != 1 && code != 5 && code != 6 && code != 10) return -1;
+  *lds = 12 * 20 * (c1->Cin * 2 + 16) + 10 * 18 * (c2->Cin * 2 + 16);
+  if (*lds > kYTileLdsMax) return -1;
+  *tiles = ((c2->Wo + 15) / 16) * ((c2->Ho + 7) / 8);
+  return code;
+}
+extern "C" int flope_ybneck_fusable(const YConvP* c1, int nt1, const YConvP* c2, int nt2) {
+  int lds, tiles;
+  return ybneck_code(c1, nt1, c2, nt2, &lds, &tiles) >= 0 ? 1 : 0;
+}
+static void ybneck_fill(YBneckP* b, const YConvP* c1, const YConvP* c2) {
+  b->c1 = *c1; b->c2 = *c2; b->tiles_x = (c2->Wo + 15) / 16; b->pad_ = 0;
+}
+template <typename T>
+static void ybneck_go(const YBneckP& b, int code, int tiles, int lds, hipStream_t st) {
+  switch (code) {
+    case 0: hipLaunchKernelGGL((ybneck_kernel<T, 1, 1>), dim3(tiles), dim3(256), lds, st, b); break;
+    case 1: hipLaunchKernelGGL((ybneck_kernel<T, 1, 2>), dim3(tiles), dim3(256), lds, st, b); break;
+    case 5: hipLaunchKernelGGL((ybneck_kernel<T, 2, 2>), dim3(tiles), dim3(256), lds, st, b); break;
+    case 6: hipLaunchKernelGGL((ybneck_kernel<T, 2, 4>), dim3(tiles), dim3(256), lds, st, b); break;
+    default: hipLaunchKernelGGL((ybneck_kernel<T, 4, 4>), dim3(tiles), dim3(256), lds, st, b); break;
+  }
+}
+extern "C" int flope_ybneck_launch(const YConvP* c1, int nt1, const YConvP* c2, int nt2, int dtype, void* stream) {
+  int lds, tiles;
+  const int code = ybneck_code(c1, nt1, c2, nt2, &lds, &tiles);
+  if (code < 0) return (int)hipErrorInvalidValue;
+  YBneckP b; ybneck_fill(&b, c1, c2);
+  if (dtype == 0) ybneck_go<bf16_t>(b, code, tiles, lds, (hipStream_t)stream); else ybneck_go<f16_t>(b, code, tiles, lds, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+extern "C" int flope_ymulti_add_bneck(YMultiP* m, const YConvP* c1, int nt1, const YConvP* c2, int nt2) {
+  int lds, tiles;
+  const int code = ybneck_code(c1, nt1, c2, nt2, &lds, &tiles);
+  if (m->n >= kYMultiMax || code < 0) return (int)hipErrorInvalidValue;
+  YMultiOp& o = m->op[m->n++];
+  o.code = 16 + code; o.nbx = tiles; o.start = m->total; o.nblocks = tiles;
+  ybneck_fill(&o.u.b, c1, c2);
+  m->lds = std::max(m->lds, lds);
+  m->total += (tiles + 7) / 8 * 8;
+  return 0;
+}
+
 extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p) {
   if (m->n >= kYMultiMax || p->C % 8) return (int)hipErrorInvalidValue;
   YMultiOp& o = m->op[m->n++];
@@ -1139,7 +1356,8 @@ extern "C" int flope_yattn_init() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define YLDS(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYTileLdsMax)
-#define YLDS_T(T) YLDS((yconv_kernel<T, 1, false, false>)); YLDS((yconv_kernel<T, 1, true, false>)); YLDS((yconv_kernel<T, 2, false, false>)); \
+#define YLDS_T(T) YLDS((ybneck_kernel<T, 1, 1>)); YLDS((ybneck_kernel<T, 1, 2>)); YLDS((ybneck_kernel<T, 2, 2>)); YLDS((ybneck_kernel<T, 2, 4>)); YLDS((ybneck_kernel<T, 4, 4>)); \
+  YLDS((yconv_kernel<T, 1, false, false>)); YLDS((yconv_kernel<T, 1, true, false>)); YLDS((yconv_kernel<T, 2, false, false>)); \
   YLDS((yconv_kernel<T, 2, true, false>)); YLDS((yconv_kernel<T, 4, false, false>)); YLDS((yconv_kernel<T, 4, true, false>)); YLDS(ymulti_kernel<T>)
   YLDS_T(bf16_t); YLDS_T(f16_t);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ysppf_lds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kYSppfLdsMax);

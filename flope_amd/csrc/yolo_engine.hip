@@ -26,6 +26,9 @@ extern "C" int flope_yconv_launch(const YConvP* p, int dtype, int nt, void* stre
 extern "C" int flope_ydw_launch(const YDwP* p, int dtype, void* stream);
 extern "C" int flope_ymulti_add_conv(YMultiP* m, const YConvP* p, int nt);
 extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p);
+extern "C" int flope_ymulti_add_bneck(YMultiP* m, const YConvP* c1, int nt1, const YConvP* c2, int nt2);
+extern "C" int flope_ybneck_fusable(const YConvP* c1, int nt1, const YConvP* c2, int nt2);
+extern "C" int flope_ybneck_launch(const YConvP* c1, int nt1, const YConvP* c2, int nt2, int dtype, void* stream);
 extern "C" int flope_ymulti_launch(const YMultiP* m, const YMultiP* m_dev, int dtype, void* stream);
 extern "C" int flope_yconv_xcd_mode(int mode);
 extern "C" int flope_yconv_tile_mode(int mode);
@@ -56,10 +59,10 @@ struct Tensor { void* ptr = nullptr; int H = 0, W = 0, C = 0; };
 struct Rng { int t, c0, c1; };                 // what an op touches: channels [c0, c1) of tensor t (t < 0: prediction-row columns)
 
 struct Op {
-  enum Kind { CONV, DW, POOL, UP, ATTN } kind;
-  int nt = 4;
+  enum Kind { CONV, DW, POOL, UP, ATTN, BNECK } kind;     // BNECK: Bottleneck cv1 -> cv2 (conv, conv2), one fused launch
+  int nt = 4, nt2 = 4;
   int level = 0;                  // longest dependency chain before this op (ops of one level are independent)
-  YConvP conv; YDwP dw; YPoolP pool; YUpP up; YAttnP attn;
+  YConvP conv, conv2; YDwP dw; YPoolP pool; YUpP up; YAttnP attn;
   std::vector<Rng> reads, writes;
   std::string name;
 };
@@ -95,6 +98,7 @@ struct flope_yolo {
   // than the overlap returned (1.31 ms; removed).  What does pay is putting the independent ops of one dependency level
   // into ONE grid (ymulti_kernel): option "batch", default on.
   int opt_batch = 1;
+  int opt_bneck = 1;                                          // 1: Bottleneck pairs as one fused launch (ybneck_kernel); 0: two conv launches
   int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
   std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // captured detect sequences, most recently used last (<= kGraphCache)
   double flops = 0.0;
@@ -332,6 +336,17 @@ struct Builder {
     const int t = tensor(vH(in), vW(in), cout(p + ".cv1"));
     conv(p + ".cv1", in, full(t), 1, 1);
     conv(p + ".cv2", full(t), out, 1, 1, &in);
+    if (rc || e->ops.size() < 2) return;
+    const Op& o2 = e->ops.back();
+    const Op& o1 = e->ops[e->ops.size() - 2];
+    if (o1.kind != Op::CONV || o2.kind != Op::CONV || !flope_ybneck_fusable(&o1.conv, o1.nt, &o2.conv, o2.nt)) return;
+    Op f; f.kind = Op::BNECK; f.name = p; f.conv = o1.conv; f.conv2 = o2.conv; f.nt = o1.nt; f.nt2 = o2.nt;
+    f.reads = o1.reads;                                   // the intermediate map never leaves the workgroup
+    for (const Rng& r : o2.reads)
+      if (r.t != t) f.reads.push_back(r);
+    f.writes = o2.writes;
+    e->ops.pop_back(); e->ops.pop_back();
+    e->ops.push_back(f);
   }
   void c3k(const std::string& p, const View& in, const View& out) {                 // cv3(cat(m(cv1(x)), cv2(x)))
     const int c_ = cout(p + ".cv1"), H = vH(in), W = vW(in);
@@ -402,6 +417,11 @@ int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
     case Op::POOL: return flope_ypool_launch(&op.pool, e->dtype, st);
     case Op::UP: return flope_yup_launch(&op.up, st);
     case Op::ATTN: return flope_yattn_launch(&op.attn, e->dtype, e->opt_generic_attn, st);
+    case Op::BNECK: {
+      if (e->opt_bneck) return flope_ybneck_launch(&op.conv, op.nt, &op.conv2, op.nt2, e->dtype, st);
+      const int s = flope_yconv_launch(&op.conv, e->dtype, op.nt, st);
+      return s ? s : flope_yconv_launch(&op.conv2, e->dtype, op.nt2, st);
+    }
   }
   return (int)hipErrorInvalidValue;
 }
@@ -451,7 +471,8 @@ int build_schedules(flope_yolo* e) {
   for (int lv = 0; lv < depth; ++lv) {
     std::vector<int> batchable, single;
     for (int i = 0; i < n; ++i)
-      if (e->ops[i].level == lv) ((e->ops[i].kind == Op::CONV || e->ops[i].kind == Op::DW) ? batchable : single).push_back(i);
+      if (e->ops[i].level == lv)
+        ((e->ops[i].kind == Op::CONV || e->ops[i].kind == Op::DW || (e->ops[i].kind == Op::BNECK && e->opt_bneck)) ? batchable : single).push_back(i);
     for (int i : single) { Launch L; L.op = i; e->sched[1].push_back(L); }
     for (size_t at = 0; at < batchable.size(); at += kYMultiMax) {
       const size_t m = std::min(batchable.size() - at, (size_t)kYMultiMax);
@@ -460,7 +481,9 @@ int build_schedules(flope_yolo* e) {
       memset(&L.multi, 0, sizeof L.multi);
       for (size_t k = 0; k < m; ++k) {
         const Op& op = e->ops[batchable[at + k]];
-        const int s = op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt) : flope_ymulti_add_dw(&L.multi, &op.dw);
+        const int s = op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt)
+                    : op.kind == Op::DW ? flope_ymulti_add_dw(&L.multi, &op.dw)
+                                        : flope_ymulti_add_bneck(&L.multi, &op.conv, op.nt, &op.conv2, op.nt2);
         if (s) return yfail(e, FLOPE_EINVAL, "schedule: cannot batch " + op.name);
         L.members.push_back(batchable[at + k]);
       }
@@ -717,7 +740,7 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   if (!e->opt_graph) return detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch, e->opt_generic_attn};
+  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch * 2 + e->opt_bneck, e->opt_generic_attn};
   hipGraphExec_t exec = nullptr;
   for (size_t i = 0; i < e->graphs.size(); ++i)
     if (memcmp(&key, &e->graphs[i].first, sizeof key) == 0) {
@@ -772,6 +795,15 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
     return prev;
   }
   if (!strcmp(name, "pool_lds")) return flope_ypool_lds_mode(value);
+  if (!strcmp(name, "bneck")) {
+    const int prev = e->opt_bneck; e->opt_bneck = value != 0;
+    if (e->loaded && prev != e->opt_bneck) {
+      if (int rc = build_schedules(e)) return rc;
+      for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
+      e->graphs.clear();
+    }
+    return prev;
+  }
   if (!strcmp(name, "batch")) { const int prev = e->opt_batch; e->opt_batch = value != 0; return prev; }
   if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
@@ -816,7 +848,8 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
                op.conv.Wo, op.conv.Cin, op.conv.Cout, op.nt, op.conv.out_mode, op.name.c_str());
     } else if (sched[i].op >= 0) {
       const Op& op = e->ops[sched[i].op];
-      snprintf(line, sizeof line, "%3zu %7.2f L%-2d %s %s\n", i, u, op.level, op.kind == Op::DW ? "dw" : op.kind == Op::POOL ? "pool" : op.kind == Op::UP ? "up" : "attn", op.name.c_str());
+      snprintf(line, sizeof line, "%3zu %7.2f L%-2d %s %s\n", i, u, op.level,
+               op.kind == Op::DW ? "dw" : op.kind == Op::POOL ? "pool" : op.kind == Op::UP ? "up" : op.kind == Op::BNECK ? "bottleneck" : "attn", op.name.c_str());
     } else {
       snprintf(line, sizeof line, "%3zu %7.2f L%-2d multi x%d (%d workgroups) %.200s\n", i, u, e->ops[sched[i].members[0]].level, sched[i].multi.n, sched[i].multi.total,
                launch_name(e, sched[i]).c_str());
