@@ -41,7 +41,7 @@ struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU
 
 // Bottleneck = cv2(cv1(x)) (+ x): two 3x3 stride-1 Conv+BN+SiLU of <= 64 channels each, fused through LDS (ybneck_body).
 // c1 / c2 are the launch parameters of the two convs exactly as the unfused path would use them (c1.out is never written).
-struct YBneckP { YConvP c1, c2; int tiles_x, pad_; };
+struct YBneckP { YConvP c1, c2; int tiles_x, th; };      // th: output rows per workgroup (8, or 4 on maps <= 4096 pixels)
 
 // ymulti_kernel: up to kYMultiMax independent conv / depthwise launches sharing one grid
 constexpr int kYMultiMax = 8;

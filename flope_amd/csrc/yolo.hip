@@ -355,51 +355,97 @@ __device__ __forceinline__ void ylds_kloop3(const char* const wrow, const int ks
   }
 }
 
+// The same with BOTH operands in LDS: weights `wl` in fragment order ([k step][channel tile][lane][16 B]).
+template <typename T, int NT, int MTW>
+__device__ __forceinline__ void ylds_kloop3w(const char* const wl, const int ksteps, const int cg, const unsigned cg_mg, const unsigned cg_sh,
+                                             const char* const lds, const int pitch, const int PW, const int (&poff)[MTW],
+                                             f32x4 (&acc)[MTW][NT]) {
+  typedef typename Elem<T>::frag frag;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int klast = ksteps - 1;
+  auto xload = [&](int ks, frag (&xf)[MTW], frag (&wf)[NT]) {
+    const int kg = ks * 4 + g;
+    const int tap = fastdiv(kg, cg_mg, cg_sh), c8 = kg - tap * cg, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    const bool tapok = tap < 9;
+    const int off = tapok ? (ky * PW + kx) * pitch + c8 * 16 : 0;
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt) {
+      frag f = *(const frag*)(lds + off + poff[pt] * pitch);
+      if (!tapok) f = frag{};
+      xf[pt] = f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(wl + ((ks * NT + ct) * 64 + lane) * 16);
+  };
+  frag xa[MTW], xb[MTW], wa[NT], wb[NT];
+  xload(0, xa, wa);
+  for (int ks = 0; ks < ksteps; ks += 2) {
+    xload(min(ks + 1, klast), xb, wb);
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wa[ct], xa[pt], acc[pt][ct]);
+    if (ks + 1 < ksteps) {
+      xload(min(ks + 2, klast), xa, wa);
+#pragma unroll
+      for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wb[ct], xb[pt], acc[pt][ct]);
+    }
+  }
+}
+
 // Bottleneck (ultralytics nn/modules/block.py): out = cv2(cv1(x)) (+ x), both 3x3 stride 1 with <= 64 output channels.  One
 // workgroup = an 8 x 16 output tile: the 12 x 20 input patch goes to LDS, cv1 is evaluated on the 10 x 18 pixels cv2 needs
 // (pixels outside the map are cv2's zero padding, not cv1 outputs), its SiLU output is parked in LDS as 16-bit NHWC and cv2
-// reads its taps from there -- one launch and no round trip of the intermediate map through memory.  Same MFMA sequence per
-// output as the two separate launches whenever those do not split K (the split-K path adds its partial sums in another order).
-template <typename T, int NT1, int NT2>
+// reads its taps from there -- one launch and no round trip of the intermediate map through memory.  The weights of a layer are
+// cold for the handful of workgroups an XCD gets (every frame walks ~130 MB between two uses), so a K loop that fetches them
+// step by step pays a memory round trip every few steps (first version: 0.4 us per K step, slower than the two launches it
+// replaced); here cv1's whole weight image is staged into LDS together with the patch (ONE round trip) and cv2's travels in
+// registers while cv1 computes.  Same MFMA sequence per output as the two separate launches whenever those do not split K (the
+// split-K path adds its partial sums in another order).
+template <typename T, int NT1, int NT2, int TH>
 __device__ __forceinline__ void ybneck_body(const YBneckP& p, const int bx, char* const lds) {
   typedef typename Elem<T>::frag frag;
-  constexpr int PD = 4, PW1 = 20, PH1 = 12, PW2 = 18, NQ = 10 * 18, MT1 = 3;
+  // TH = 8 or 4 output rows per workgroup (4 on the small maps: twice the workgroups, shorter serial chains)
+  constexpr int PW1 = 20, PH1 = TH + 4, PW2 = 18, NQ = (TH + 2) * 18, MT1 = (NQ + 63) / 64, MT2 = TH / 4;
+  constexpr int WV1 = (18 * NT1 * 64 + 255) / 256, WV2 = (18 * NT2 * 64 + 255) / 256, PV = (PH1 * PW1 * 8 + 255) / 256;   // 16-byte chunks per thread (ksteps <= 18, Cin <= 64)
   const YConvP& c1 = p.c1;
   const YConvP& c2 = p.c2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;
-  const int oy0 = ty * 8, ox0 = tx * 16;
+  const int oy0 = ty * TH, ox0 = tx * 16;
   const int pitch1 = c1.Cin * 2 + 16, pitch2 = c2.Cin * 2 + 16;
   char* const mid = lds + PH1 * PW1 * pitch1;
-  const char* const wrow1 = (const char*)c1.w + lane * 16;
-  const char* const wrow2 = (const char*)c2.w + lane * 16;
-  frag wf1[PD][NT1];
-#pragma unroll
-  for (int s_ = 0; s_ < PD; ++s_)
-#pragma unroll
-    for (int ct = 0; ct < NT1; ++ct) wf1[s_][ct] = *(const frag*)(wrow1 + (size_t)(min(s_, c1.ksteps - 1) * NT1 + ct) * 1024);
+  char* const wl = mid + NQ * pitch2;                       // weight image: cv1's, then cv2's
+  const int nw1 = c1.ksteps * NT1 * 64, nw2 = c2.ksteps * NT2 * 64;
   {
+    u32x4 wv[WV1], pv_[PV];
     const int total = PH1 * PW1 * c1.cg;
     const char* const in = (const char*)c1.in;
-    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
-      u32x4 v[4];
-      int dst[4];
+    int dst[PV];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = i0 + j * 256, ic = min(i, total - 1);
-        const int pp = fastdiv(ic, c1.cg_mg, c1.cg_sh), c8 = ic - pp * c1.cg;
-        const int py = pp / PW1, px = pp - py * PW1;
-        const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
-        const bool ok = (unsigned)iy < (unsigned)c1.Hi && (unsigned)ix < (unsigned)c1.Wi;
-        v[j] = ok ? *(const u32x4*)(in + ((size_t)(iy * c1.Wi + ix) * c1.ldi + c8 * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
-        dst[j] = i < total ? pp * pitch1 + c8 * 16 : -1;
-      }
+    for (int j = 0; j < WV1; ++j) { const int i = tid + j * 256; if (i < nw1) wv[j] = *(const u32x4*)((const char*)c1.w + (size_t)i * 16); }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (dst[j] >= 0) *(u32x4*)(lds + dst[j]) = v[j];
+    for (int j = 0; j < PV; ++j) {
+      const int i = tid + j * 256, ic = min(i, total - 1);
+      const int pp = fastdiv(ic, c1.cg_mg, c1.cg_sh), c8 = ic - pp * c1.cg;
+      const int py = pp / PW1, px = pp - py * PW1;
+      const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+      const bool ok = i < total && (unsigned)iy < (unsigned)c1.Hi && (unsigned)ix < (unsigned)c1.Wi;
+      pv_[j] = ok ? *(const u32x4*)(in + ((size_t)(iy * c1.Wi + ix) * c1.ldi + c8 * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+      dst[j] = i < total ? pp * pitch1 + c8 * 16 : -1;
     }
+#pragma unroll
+    for (int j = 0; j < PV; ++j)
+      if (dst[j] >= 0) *(u32x4*)(lds + dst[j]) = pv_[j];
+#pragma unroll
+    for (int j = 0; j < WV1; ++j) { const int i = tid + j * 256; if (i < nw1) *(u32x4*)(wl + (size_t)i * 16) = wv[j]; }
   }
+  u32x4 wv2[WV2];                                           // cv2's weights: in flight while cv1 computes
+#pragma unroll
+  for (int j = 0; j < WV2; ++j) { const int i = tid + j * 256; if (i < nw2) wv2[j] = *(const u32x4*)((const char*)c2.w + (size_t)i * 16); }
   __syncthreads();
   // ---- cv1 on the 10 x 18 intermediate pixels: wave w owns pixel tiles w, w + 4, w + 8 (flat index q, row-major 18 wide)
   int q[MT1], poff1[MT1];
@@ -416,12 +462,10 @@ __device__ __forceinline__ void ybneck_body(const YBneckP& p, const int bx, char
 #pragma unroll
     for (int j = 0; j < MT1; ++j) acc1[j][ct] = b;
   }
-  ylds_kloop3<T, NT1, MT1>(wrow1, c1.ksteps, c1.cg, c1.cg_mg, c1.cg_sh, lds, pitch1, PW1, poff1, wf1, acc1);
-  frag wf2[PD][NT2];                                        // cv2's first weights travel while cv1's epilogue runs
+  ylds_kloop3w<T, NT1, MT1>(wl, c1.ksteps, c1.cg, c1.cg_mg, c1.cg_sh, lds, pitch1, PW1, poff1, acc1);
+  __syncthreads();                                          // every wave is done with cv1's weights
 #pragma unroll
-  for (int s_ = 0; s_ < PD; ++s_)
-#pragma unroll
-    for (int ct = 0; ct < NT2; ++ct) wf2[s_][ct] = *(const frag*)(wrow2 + (size_t)(min(s_, c2.ksteps - 1) * NT2 + ct) * 1024);
+  for (int j = 0; j < WV2; ++j) { const int i = tid + j * 256; if (i < nw2) *(u32x4*)(wl + (size_t)i * 16) = wv2[j]; }
   {
     const int ch0 = g * 4 * NT1;
 #pragma unroll
@@ -440,34 +484,35 @@ __device__ __forceinline__ void ybneck_body(const YBneckP& p, const int bx, char
     }
   }
   __syncthreads();
-  // ---- cv2 on the 8 x 16 output pixels: wave w owns rows 2w, 2w + 1
-  int poff2[2];
+  // ---- cv2 on the TH x 16 output pixels: wave w owns rows MT2 w .. MT2 w + MT2 - 1
+  int poff2[MT2];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) poff2[pt] = (wave * 2 + pt) * PW2 + c16;
-  f32x4 acc2[2][NT2];
+  for (int pt = 0; pt < MT2; ++pt) poff2[pt] = (wave * MT2 + pt) * PW2 + c16;
+  f32x4 acc2[MT2][NT2];
 #pragma unroll
   for (int ct = 0; ct < NT2; ++ct) {
     const f32x4 b = *(const f32x4*)(c2.bias + ct * 16 + g * 4);
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) acc2[pt][ct] = b;
+    for (int pt = 0; pt < MT2; ++pt) acc2[pt][ct] = b;
   }
-  ylds_kloop3<T, NT2, 2>(wrow2, c2.ksteps, c2.cg, c2.cg_mg, c2.cg_sh, mid, pitch2, PW2, poff2, wf2, acc2);
-  int mm[2];
-  bool pv[2];
+  ylds_kloop3w<T, NT2, MT2>(wl, c2.ksteps, c2.cg, c2.cg_mg, c2.cg_sh, mid, pitch2, PW2, poff2, acc2);
+  int mm[MT2];
+  bool pv[MT2];
   const int ox = ox0 + c16;
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int oy = oy0 + wave * 2 + pt;
+  for (int pt = 0; pt < MT2; ++pt) {
+    const int oy = oy0 + wave * MT2 + pt;
     pv[pt] = oy < c2.Ho && ox < c2.Wo;
     mm[pt] = oy * c2.Wo + ox;
   }
-  yconv_epilogue<T, NT2, 2>(c2, 0, g, mm, pv, acc2);
+  yconv_epilogue<T, NT2, MT2>(c2, 0, g, mm, pv, acc2);
 }
 
 template <typename T, int NT1, int NT2>
 __global__ __launch_bounds__(256) void ybneck_kernel(const YBneckP p) {
   extern __shared__ __attribute__((aligned(16))) char ylds[];
-  ybneck_body<T, NT1, NT2>(p, blockIdx.x, ylds);
+  if (p.th == 4) ybneck_body<T, NT1, NT2, 4>(p, blockIdx.x, ylds);
+  else ybneck_body<T, NT1, NT2, 8>(p, blockIdx.x, ylds);
 }
 
 // Workgroups are handed to the 8 XCDs round-robin (flat id mod 8), each XCD with its own 4 MiB L2.  On the large maps the
@@ -552,11 +597,13 @@ __global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP* __restrict__
   if (o.code == 12) { ydw_body<T>(o.u.d, lb); return; }
   if (o.code >= 16) {
     switch (o.code - 16) {                               // (NT1 index) * 4 + (NT2 index)
-      case 0: ybneck_body<T, 1, 1>(o.u.b, lb, ylds); break;
-      case 1: ybneck_body<T, 1, 2>(o.u.b, lb, ylds); break;
-      case 5: ybneck_body<T, 2, 2>(o.u.b, lb, ylds); break;
-      case 6: ybneck_body<T, 2, 4>(o.u.b, lb, ylds); break;
-      default: ybneck_body<T, 4, 4>(o.u.b, lb, ylds); break;
+#define YB(N1, N2) do { if (o.u.b.th == 4) ybneck_body<T, N1, N2, 4>(o.u.b, lb, ylds); else ybneck_body<T, N1, N2, 8>(o.u.b, lb, ylds); } while (0)
+      case 0: YB(1, 1); break;
+      case 1: YB(1, 2); break;
+      case 5: YB(2, 2); break;
+      case 6: YB(2, 4); break;
+      default: YB(4, 4); break;
+#undef YB
     }
     return;
   }
@@ -1203,7 +1250,7 @@ static int g_splitk_max_m = 8192;                           // split-K (one 32-p
 extern "C" int flope_yconv_splitk_max_m(int m) { const int prev = g_splitk_max_m; if (m >= 0) g_splitk_max_m = m; return prev; }
 static int g_tile_mode = 1;                                  // 1: LDS-staged 8 x 16 tiles for every non-split-K conv; 0: fragments from global
 extern "C" int flope_yconv_tile_mode(int mode) { const int prev = g_tile_mode; if (mode == 0 || mode == 1) g_tile_mode = mode; return prev; }
-constexpr int kYTileLdsMax = 96 * 1024;
+constexpr int kYTileLdsMax = 96 * 1024, kYBneckLdsMax = 144 * 1024;
 
 // fills the launch-derived fields of *q (tile, tiles_x, pw_*), -> split-K?, grid, dynamic LDS bytes
 static bool yconv_geometry(const YConvP* p, int nt, YConvP* q, bool* splitk, int* nbx, int* nby, int* lds) {
@@ -1264,9 +1311,11 @@ static int ybneck_code(const YConvP* c1, int nt1, const YConvP* c2, int nt2, int
   if (c1->Ho != c2->Hi || c1->Wo != c2->Wi || c1->Cout > 16 * nt1 || c2->Cout > 16 * nt2 || c2->Cin != c1->Cout) return -1;
   const int i1 = nt1 == 1 ? 0 : nt1 == 2 ? 1 : 2, i2 = nt2 == 1 ? 0 : nt2 == 2 ? 1 : 2, code = i1 * 4 + i2;
   if (code != 0 && code != 1 && code != 5 && code != 6 && code != 10) return -1;
-  *lds = 12 * 20 * (c1->Cin * 2 + 16) + 10 * 18 * (c2->Cin * 2 + 16);
-  if (*lds > kYTileLdsMax) return -1;
-  *tiles = ((c2->Wo + 15) / 16) * ((c2->Ho + 7) / 8);
+  if (c1->ksteps > 18 || c2->ksteps > 18 || c1->Cin > 64) return -1;
+  const int th = c2->M <= 4096 ? 4 : 8;                       // small maps: 4-row tiles (twice the workgroups, shorter chains)
+  *lds = (th + 4) * 20 * (c1->Cin * 2 + 16) + (th + 2) * 18 * (c2->Cin * 2 + 16) + std::max(c1->ksteps * nt1, c2->ksteps * nt2) * 1024;
+  if (*lds > kYBneckLdsMax) return -1;
+  *tiles = ((c2->Wo + 15) / 16) * ((c2->Ho + th - 1) / th);
   return code;
 }
 extern "C" int flope_ybneck_fusable(const YConvP* c1, int nt1, const YConvP* c2, int nt2) {
@@ -1274,7 +1323,7 @@ extern "C" int flope_ybneck_fusable(const YConvP* c1, int nt1, const YConvP* c2,
   return ybneck_code(c1, nt1, c2, nt2, &lds, &tiles) >= 0 ? 1 : 0;
 }
 static void ybneck_fill(YBneckP* b, const YConvP* c1, const YConvP* c2) {
-  b->c1 = *c1; b->c2 = *c2; b->tiles_x = (c2->Wo + 15) / 16; b->pad_ = 0;
+  b->c1 = *c1; b->c2 = *c2; b->tiles_x = (c2->Wo + 15) / 16; b->th = c2->M <= 4096 ? 4 : 8;
 }
 template <typename T>
 static void ybneck_go(const YBneckP& b, int code, int tiles, int lds, hipStream_t st) {
@@ -1356,14 +1405,16 @@ extern "C" int flope_yattn_init() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define YLDS(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYTileLdsMax)
-#define YLDS_T(T) YLDS((ybneck_kernel<T, 1, 1>)); YLDS((ybneck_kernel<T, 1, 2>)); YLDS((ybneck_kernel<T, 2, 2>)); YLDS((ybneck_kernel<T, 2, 4>)); YLDS((ybneck_kernel<T, 4, 4>)); \
+#define YLDSB(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYBneckLdsMax)
+#define YLDS_T(T) YLDSB((ybneck_kernel<T, 1, 1>)); YLDSB((ybneck_kernel<T, 1, 2>)); YLDSB((ybneck_kernel<T, 2, 2>)); YLDSB((ybneck_kernel<T, 2, 4>)); YLDSB((ybneck_kernel<T, 4, 4>)); YLDSB(ymulti_kernel<T>); \
   YLDS((yconv_kernel<T, 1, false, false>)); YLDS((yconv_kernel<T, 1, true, false>)); YLDS((yconv_kernel<T, 2, false, false>)); \
-  YLDS((yconv_kernel<T, 2, true, false>)); YLDS((yconv_kernel<T, 4, false, false>)); YLDS((yconv_kernel<T, 4, true, false>)); YLDS(ymulti_kernel<T>)
+  YLDS((yconv_kernel<T, 2, true, false>)); YLDS((yconv_kernel<T, 4, false, false>)); YLDS((yconv_kernel<T, 4, true, false>))
   YLDS_T(bf16_t); YLDS_T(f16_t);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ysppf_lds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kYSppfLdsMax);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ysppf_lds_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kYSppfLdsMax);
 #undef YLDS_T
 #undef YLDS
+#undef YLDSB
   return (int)e;
 }
 

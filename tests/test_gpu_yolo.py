@@ -120,6 +120,31 @@ def test_lds_tile_path_equals_the_global_fragment_path(ysd):
         y.close()
 
 
+def test_fused_bottleneck_equals_two_conv_launches(ysd):
+    """Bottleneck pairs (3x3 -> 3x3, <= 64 channels) run as ONE launch with the intermediate map in LDS (default); option
+    bneck=0 launches the two convs.  On the large maps (no split-K in the unfused path) the MFMA sequence per output is the
+    same: bit-identical.  On the small maps the unfused path splits K over four waves and adds the partial sums in another
+    order: equal to fp32 summation order (one 16-bit rounding of a few outputs may flip)."""
+    from flope_amd.yolo_weights import synthetic_frame
+    for (H, W, imgsz) in ((1080, 1920, 1280), (360, 640, 640), (250, 333, 320)):
+        img = synthetic_frame(12, H, W)
+        y = _engine(ysd, H, W, imgsz)
+        names = ("2", "4", "6", "8", "13", "16", "19", "22", "proto", "box0", "cls1", "coef2")
+        outs = []
+        for bneck in (1, 0):
+            assert y.set_option("bneck", bneck) in (0, 1)
+            y.forward(img)
+            outs.append({k: y.read_tensor(k).cpu() for k in names})
+        y.set_option("bneck", 1)
+        for k in names:
+            a, b = outs[0][k], outs[1][k]
+            assert _rel(a, b) <= 2e-3, (k, _rel(a, b))
+        if imgsz == 1280:
+            assert torch.equal(outs[0]["2"], outs[1]["2"])            # 184 x 320 map: the unfused path does not split K either
+        assert y.launches() < 75
+        y.close()
+
+
 def _head_rows(y):
     """the device's own float32 head rows as the oracle's `o` dict"""
     o = {}
