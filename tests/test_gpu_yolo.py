@@ -331,6 +331,33 @@ def test_pipelined_live_loop_equals_the_sequential_one(ysd, state_dict, tmp_path
     assert len(live_pose_loop(pred, frames[:5], pipelined=True)) == 5
 
 
+def test_detector_on_a_cu_masked_stream(ysd):
+    """flope_stream_create_cu_mask: a stream restricted to 64 of the 256 CUs runs the same launches (the multi-op grids and
+    the persistent-free kernels do not depend on the CU count): identical detections; bad masks are rejected."""
+    import ctypes as C
+    from flope_amd import _lib
+    from flope_amd.yolo_weights import synthetic_frame
+    lib = _lib.load()
+    img = synthetic_frame(13, 360, 640)
+    y = _engine(ysd, 360, 640, 640)
+    ref = y.detect(img, 0.05)
+    mask = (C.c_uint32 * 8)(*([0xFFFFFFFF, 0xFFFFFFFF] + [0] * 6))
+    h = C.c_void_p()
+    assert lib.flope_stream_create_cu_mask(0, mask, 8, C.byref(h)) == 0 and h.value
+    st = torch.cuda.ExternalStream(h.value)
+    with torch.cuda.stream(st):
+        got = y.detect(img, 0.05)
+    st.synchronize()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert len(ref[0]) >= 3
+    assert lib.flope_stream_destroy(0, h) == 0
+    zero = (C.c_uint32 * 8)()
+    assert lib.flope_stream_create_cu_mask(0, zero, 8, C.byref(h)) != 0
+    assert lib.flope_stream_create_cu_mask(0, None, 8, C.byref(h)) != 0
+    y.close()
+
+
 def test_yolo_error_paths(ysd):
     from flope_amd.yolo import YoloSeg
     with pytest.raises(RuntimeError, match="imgsz"):
