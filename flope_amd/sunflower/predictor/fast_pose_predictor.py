@@ -121,7 +121,7 @@ class FastPosePredictor:
             sd, ck_imgsz = load_yolo_checkpoint(str(yolo_path))
             # ultralytics predicts at the size the checkpoint was trained with (the reference's is `yolo11nseg_1280.pt`, :177)
             self._yolo_args = (sd, int(imgsz or ck_imgsz or 1280), yolo_dtype)
-            self._yolo_b = None                # second detector instance of the pipelined loop, built on first use
+            self._yolo_more = []               # further detector instances of the pipelined loop, built on first use
             self.yolo = YoloSeg(int(self.height), int(self.width), self._yolo_args[1], yolo_dtype, device=device)
             self.yolo.load_state_dict(sd)
             self._detector = self.yolo.get_bbox_mask
@@ -148,7 +148,7 @@ class FastPosePredictor:
 
     def iter_flower_poses(self, frames, detectors: int = 2):
         """`get_flower_poses` over a stream of (rgb, depth) frames, software-pipelined.  The detector is a chain of ~75 short,
-        narrow launches that leaves most of the GPU idle, so `detectors` (1 or 2) instances of it work on consecutive frames
+        narrow launches that leaves most of the GPU idle, so `detectors` (1..4, default 2) instances of it work on consecutive frames
         on their own HIP streams (replaying captured hipGraphs: one host call per frame) while crops -> PoseResNet ->
         Procrustes of an earlier frame run on another stream and the uploads of the next frame on a third; the host only ever
         waits for the oldest detector.  Yields exactly what get_flower_poses returns, frame by frame, in order,
@@ -159,13 +159,14 @@ class FastPosePredictor:
                 yield self.get_flower_poses(rgb, depth)
             return
         dev = torch.device(self.device)
-        nd = 2 if detectors >= 2 else 1
-        if nd == 2 and self._yolo_b is None:
+        nd = max(1, min(int(detectors), 4))
+        while len(self._yolo_more) < nd - 1:
             from flope_amd.yolo import YoloSeg
             sd, imgsz, dt = self._yolo_args
-            self._yolo_b = YoloSeg(self.yolo.frame_h, self.yolo.frame_w, imgsz, dt, device=self.device)
-            self._yolo_b.load_state_dict(sd)
-        dets = [self.yolo, self._yolo_b][:nd]
+            extra = YoloSeg(self.yolo.frame_h, self.yolo.frame_w, imgsz, dt, device=self.device)
+            extra.load_state_dict(sd)
+            self._yolo_more.append(extra)
+        dets = [self.yolo] + self._yolo_more[:nd - 1]
         s_io, s_pose = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         s_det = [torch.cuda.Stream(dev) for _ in range(nd)]
         H, W = self.yolo.frame_h, self.yolo.frame_w

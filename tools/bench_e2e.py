@@ -54,7 +54,7 @@ def main_yolo(tmp, ckpt, intr):
     print(f"[e2e+yolo] 1080p frame -> {bb.shape[0]} detections -> {0 if Rt is None else Rt.shape[0]} poses (512x512 crops): "
           f"{dt*1e3:.2f} ms/frame, {1/dt:.1f} frames/s; get_bbox_mask alone (numpy in, numpy out) {dd*1e3:.2f} ms", flush=True)
     frames = [(rgb, depth)] * 120
-    for nd in (1, 2):
+    for nd in (1, 2, 3):
         list(pred.iter_flower_poses(frames[:12], detectors=nd))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
