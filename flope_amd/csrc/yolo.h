@@ -26,6 +26,7 @@ struct YConvP {
   int dc;                                    // out_mode 2: real output channels (rows = 4 * dc, row = (dy*2+dx)*dc + co)
   int xcd;                                   // set by the launcher: workgroup order remapped so that an XCD owns an image band
   int tile, tiles_x;                         // set by the launcher: LDS-staged 8 x 16 output tiles; tiles per row
+  int wlds, pad2_;                           // set by the launcher: tile path with the weight image staged in LDS as well
   unsigned pw_mg, pw_sh;                     // n / (patch width) as multiply-shift
 };
 

@@ -202,6 +202,11 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
   yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
 }
 
+template <typename T, int NT, int MTW>
+__device__ __forceinline__ void ylds_kloop3w(const char* const wl, const int ksteps, const int cg, const unsigned cg_mg, const unsigned cg_sh,
+                                             const char* const lds, const int pitch, const int PW, const int (&poff)[MTW],
+                                             f32x4 (&acc)[MTW][NT]);
+
 // ---------------------------------------------------------------------------------------------------------------
 // Large maps (everything that is not SPLITK): one workgroup = an 8-row x 16-column tile of output pixels, wave w owns rows
 // 2w and 2w+1.  The input patch ((7 s + k) x (15 s + k) pixels, all channels) is staged once into LDS with fully coalesced
@@ -223,6 +228,59 @@ __device__ __forceinline__ void yconv_tile_body(const YConvP& p, const int bx, c
   const int nblk = by;
   const char* const wrow = (const char*)p.w + (size_t)nblk * p.ksteps * (NT * 1024) + lane * 16;
   const int klast = p.ksteps - 1;
+  if constexpr (K3) {
+    // Long K (>= 8 steps): the layer's weights are cold for the one or two workgroups an XCD gets, and a K loop that fetches them
+    // PD steps ahead pays a memory round trip every PD steps.  Stage the channel block's whole weight image into LDS together with
+    // the patch (one round trip) and run the K loop on LDS operands only.
+    if (p.wlds) {
+      char* const wl = lds + PH * PW * pitch;
+      const int nw = p.ksteps * NT * 64, total = PH * PW * p.cg;
+      const char* const wsrc = (const char*)p.w + (size_t)nblk * p.ksteps * (NT * 1024);
+      const char* const in = (const char*)p.in;
+      for (int i0 = tid; i0 < nw + total; i0 += 8 * 256) {
+        u32x4 v[8];
+        int dst[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = i0 + j * 256;
+          if (i < nw) { v[j] = *(const u32x4*)(wsrc + (size_t)i * 16); dst[j] = PH * PW * pitch + i * 16; continue; }
+          const int ip = min(i - nw, total - 1);
+          const int pp = fastdiv(ip, p.cg_mg, p.cg_sh), c8 = ip - pp * p.cg;
+          const int py = fastdiv(pp, p.pw_mg, p.pw_sh), px = pp - py * PW;
+          const int iy = iy00 + py, ix = ix00 + px;
+          const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+          v[j] = ok ? *(const u32x4*)(in + ((size_t)(iy * p.Wi + ix) * p.ldi + c8 * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+          dst[j] = i - nw < total ? pp * pitch + c8 * 16 : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (dst[j] >= 0) *(u32x4*)(lds + dst[j]) = v[j];
+      }
+      __syncthreads();
+      int poff[MTW];
+#pragma unroll
+      for (int pt = 0; pt < MTW; ++pt) poff[pt] = ((wave * 2 + pt) * s) * PW + c16 * s;
+      f32x4 accw[MTW][NT];
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const f32x4 b = *(const f32x4*)(p.bias + nblk * (16 * NT) + ct * 16 + g * 4);
+#pragma unroll
+        for (int pt = 0; pt < MTW; ++pt) accw[pt][ct] = b;
+      }
+      ylds_kloop3w<T, NT, MTW>(wl, p.ksteps, p.cg, p.cg_mg, p.cg_sh, lds, pitch, PW, poff, accw);
+      int mm[MTW];
+      bool pv[MTW];
+      const int ox = tx * 16 + c16;
+#pragma unroll
+      for (int pt = 0; pt < MTW; ++pt) {
+        const int oy = ty * 8 + wave * 2 + pt;
+        pv[pt] = oy < p.Ho && ox < p.Wo;
+        mm[pt] = oy * p.Wo + ox;
+      }
+      yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, accw);
+      return;
+    }
+  }
   frag wf[PD][NT];
 #pragma unroll
   for (int s_ = 0; s_ < PD; ++s_)
@@ -1248,9 +1306,12 @@ static void yconv_go(const YConvP& p, int nt, bool splitk, dim3 grid, int lds, h
 
 static int g_splitk_max_m = 8192;                           // split-K (one 32-pixel tile per workgroup, K over its 4 waves) up to this map size
 extern "C" int flope_yconv_splitk_max_m(int m) { const int prev = g_splitk_max_m; if (m >= 0) g_splitk_max_m = m; return prev; }
+static int g_wlds_mode = 0;                                  // 1: tile path, 3x3, >= 8 K steps keeps the weight image in LDS too (measured
+                                                             // slower: 0.78 vs 0.74 ms -- 96 KB of LDS leave one workgroup per CU on the large maps)
+extern "C" int flope_yconv_wlds_mode(int mode) { const int prev = g_wlds_mode; if (mode == 0 || mode == 1) g_wlds_mode = mode; return prev; }
 static int g_tile_mode = 1;                                  // 1: LDS-staged 8 x 16 tiles for every non-split-K conv; 0: fragments from global
 extern "C" int flope_yconv_tile_mode(int mode) { const int prev = g_tile_mode; if (mode == 0 || mode == 1) g_tile_mode = mode; return prev; }
-constexpr int kYTileLdsMax = 96 * 1024, kYBneckLdsMax = 144 * 1024;
+constexpr int kYTileLdsMax = 96 * 1024, kYBneckLdsMax = 144 * 1024;   // patch alone; patch + weight image(s)
 
 // fills the launch-derived fields of *q (tile, tiles_x, pw_*), -> split-K?, grid, dynamic LDS bytes
 static bool yconv_geometry(const YConvP* p, int nt, YConvP* q, bool* splitk, int* nbx, int* nby, int* lds) {
@@ -1262,11 +1323,14 @@ static bool yconv_geometry(const YConvP* p, int nt, YConvP* q, bool* splitk, int
   *nby = (rows + 16 * nt - 1) / (16 * nt);
   const int PW = 15 * p->stride + p->k, PH = 7 * p->stride + p->k, patch = PH * PW * (p->Cin * 2 + 16);
   q->tile = (!*splitk && g_tile_mode && patch <= kYTileLdsMax) ? 1 : 0;
+  q->wlds = 0;
   if (q->tile) {
     q->tiles_x = (p->Wo + 15) / 16;
     *nbx = q->tiles_x * ((p->Ho + 7) / 8);
     flope_host::fastdiv_magic((unsigned)PW, &q->pw_mg, &q->pw_sh);
     *lds = patch;
+    const int wbytes = p->ksteps * nt * 1024;
+    if (g_wlds_mode && p->k == 3 && p->ksteps >= 8 && patch + wbytes <= kYBneckLdsMax) { q->wlds = 1; *lds = patch + wbytes; }
   } else {
     *nbx = *splitk ? (p->M + 31) / 32 : (p->M + 127) / 128;
     *lds = *splitk ? 3 * 2 * nt * 4 * 64 * 4 : 0;
@@ -1404,7 +1468,7 @@ extern "C" int flope_yattn_init() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)yattn_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define YLDS(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYTileLdsMax)
+#define YLDS(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYBneckLdsMax)
 #define YLDSB(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kYBneckLdsMax)
 #define YLDS_T(T) YLDSB((ybneck_kernel<T, 1, 1>)); YLDSB((ybneck_kernel<T, 1, 2>)); YLDSB((ybneck_kernel<T, 2, 2>)); YLDSB((ybneck_kernel<T, 2, 4>)); YLDSB((ybneck_kernel<T, 4, 4>)); YLDSB(ymulti_kernel<T>); \
   YLDS((yconv_kernel<T, 1, false, false>)); YLDS((yconv_kernel<T, 1, true, false>)); YLDS((yconv_kernel<T, 2, false, false>)); \

@@ -34,6 +34,7 @@ extern "C" int flope_yconv_xcd_mode(int mode);
 extern "C" int flope_yconv_tile_mode(int mode);
 extern "C" int flope_yconv_splitk_max_m(int m);
 extern "C" int flope_ypool_lds_mode(int mode);
+extern "C" int flope_yconv_wlds_mode(int mode);
 extern "C" int flope_ypool_launch(const YPoolP* p, int dtype, void* stream);
 extern "C" int flope_yup_launch(const YUpP* p, void* stream);
 extern "C" int flope_yattn_init();
@@ -469,30 +470,38 @@ int build_schedules(flope_yolo* e) {
   e->sched[0].clear(); e->sched[1].clear();
   for (int i = 0; i < n; ++i) { Launch L; L.op = i; e->sched[0].push_back(L); }
   for (int lv = 0; lv < depth; ++lv) {
-    std::vector<int> batchable, single;
+    // one grid's dynamic LDS is that of its hungriest op, so a fused Bottleneck (up to 134 KB) leaves the plain convs it shares a
+    // grid with one workgroup per CU -- measured, sharing still wins (0.741 vs 0.757 ms per frame: a launch less per level);
+    // bneck = 2 keeps them in grids of their own
+    std::vector<int> classes[2], single;
     for (int i = 0; i < n; ++i)
-      if (e->ops[i].level == lv)
-        ((e->ops[i].kind == Op::CONV || e->ops[i].kind == Op::DW || (e->ops[i].kind == Op::BNECK && e->opt_bneck)) ? batchable : single).push_back(i);
-    for (int i : single) { Launch L; L.op = i; e->sched[1].push_back(L); }
-    for (size_t at = 0; at < batchable.size(); at += kYMultiMax) {
-      const size_t m = std::min(batchable.size() - at, (size_t)kYMultiMax);
-      Launch L;
-      if (m == 1) { L.op = batchable[at]; e->sched[1].push_back(L); continue; }
-      memset(&L.multi, 0, sizeof L.multi);
-      for (size_t k = 0; k < m; ++k) {
-        const Op& op = e->ops[batchable[at + k]];
-        const int s = op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt)
-                    : op.kind == Op::DW ? flope_ymulti_add_dw(&L.multi, &op.dw)
-                                        : flope_ymulti_add_bneck(&L.multi, &op.conv, op.nt, &op.conv2, op.nt2);
-        if (s) return yfail(e, FLOPE_EINVAL, "schedule: cannot batch " + op.name);
-        L.members.push_back(batchable[at + k]);
+      if (e->ops[i].level == lv) {
+        const Op& op = e->ops[i];
+        if (op.kind == Op::CONV || op.kind == Op::DW) classes[0].push_back(i);
+        else if (op.kind == Op::BNECK && e->opt_bneck) classes[e->opt_bneck == 2 ? 1 : 0].push_back(i);
+        else single.push_back(i);
       }
-      if (hipMalloc((void**)&L.multi_dev, sizeof(YMultiP)) != hipSuccess ||
-          hipMemcpy(L.multi_dev, &L.multi, sizeof(YMultiP), hipMemcpyHostToDevice) != hipSuccess)
-        return yfail(e, FLOPE_EHIP, "schedule: parameter table upload failed");
-      e->owned.push_back(L.multi_dev);
-      e->sched[1].push_back(L);
-    }
+    for (int i : single) { Launch L; L.op = i; e->sched[1].push_back(L); }
+    for (const std::vector<int>& batchable : classes)
+      for (size_t at = 0; at < batchable.size(); at += kYMultiMax) {
+        const size_t m = std::min(batchable.size() - at, (size_t)kYMultiMax);
+        Launch L;
+        if (m == 1) { L.op = batchable[at]; e->sched[1].push_back(L); continue; }
+        memset(&L.multi, 0, sizeof L.multi);
+        for (size_t k = 0; k < m; ++k) {
+          const Op& op = e->ops[batchable[at + k]];
+          const int s = op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt)
+                      : op.kind == Op::DW ? flope_ymulti_add_dw(&L.multi, &op.dw)
+                                          : flope_ymulti_add_bneck(&L.multi, &op.conv, op.nt, &op.conv2, op.nt2);
+          if (s) return yfail(e, FLOPE_EINVAL, "schedule: cannot batch " + op.name);
+          L.members.push_back(batchable[at + k]);
+        }
+        if (hipMalloc((void**)&L.multi_dev, sizeof(YMultiP)) != hipSuccess ||
+            hipMemcpy(L.multi_dev, &L.multi, sizeof(YMultiP), hipMemcpyHostToDevice) != hipSuccess)
+          return yfail(e, FLOPE_EHIP, "schedule: parameter table upload failed");
+        e->owned.push_back(L.multi_dev);
+        e->sched[1].push_back(L);
+      }
   }
   return FLOPE_OK;
 }
@@ -740,7 +749,7 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   if (!e->opt_graph) return detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch * 2 + e->opt_bneck, e->opt_generic_attn};
+  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch * 4 + e->opt_bneck, e->opt_generic_attn};
   hipGraphExec_t exec = nullptr;
   for (size_t i = 0; i < e->graphs.size(); ++i)
     if (memcmp(&key, &e->graphs[i].first, sizeof key) == 0) {
@@ -785,8 +794,9 @@ extern "C" int flope_yolo_read_tensor(flope_yolo_handle e, const char* name, flo
 extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int value) {
   if (!e || !name) return yfail(e, FLOPE_EINVAL, "flope_yolo_set_option: NULL argument");
   if (!strcmp(name, "generic_attn")) { const int prev = e->opt_generic_attn; e->opt_generic_attn = value != 0; return prev; }
-  if (!strcmp(name, "xcd") || !strcmp(name, "tile") || !strcmp(name, "splitk_max_m")) {   // process-wide A/B knobs; the batched schedule bakes them in
-    const int prev = !strcmp(name, "xcd") ? flope_yconv_xcd_mode(value) : !strcmp(name, "tile") ? flope_yconv_tile_mode(value) : flope_yconv_splitk_max_m(value);
+  if (!strcmp(name, "xcd") || !strcmp(name, "tile") || !strcmp(name, "splitk_max_m") || !strcmp(name, "wlds")) {   // process-wide A/B knobs; the batched schedule bakes them in
+    const int prev = !strcmp(name, "xcd") ? flope_yconv_xcd_mode(value) : !strcmp(name, "tile") ? flope_yconv_tile_mode(value)
+                   : !strcmp(name, "wlds") ? flope_yconv_wlds_mode(value) : flope_yconv_splitk_max_m(value);
     if (e->loaded) {
       if (int rc = build_schedules(e)) return rc;
       for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
@@ -796,7 +806,7 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
   }
   if (!strcmp(name, "pool_lds")) return flope_ypool_lds_mode(value);
   if (!strcmp(name, "bneck")) {
-    const int prev = e->opt_bneck; e->opt_bneck = value != 0;
+    const int prev = e->opt_bneck; e->opt_bneck = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (e->loaded && prev != e->opt_bneck) {
       if (int rc = build_schedules(e)) return rc;
       for (auto& g : e->graphs) hipGraphExecDestroy(g.second);

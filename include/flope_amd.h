@@ -244,12 +244,13 @@ int flope_yolo_read_tensor(flope_yolo_handle h, const char* name, float* dst_dev
  *       coefficient branches of a level, the Proto block beside them, parallel 1x1 convs inside C3k) share one grid; 0: one
  *       launch per op in the program order of the ultralytics yaml;
  *   "bneck" (default 1): Bottleneck pairs (3x3 -> 3x3, <= 64 channels) as one fused launch with the intermediate map in LDS;
- *       0: two conv launches;
+ *       2: fused, but never in one grid with plain convs; 0: two conv launches;
  *   "generic_attn" (default 0): C2PSA attention on the generic fp32 kernel instead of the MFMA one;
  *   A/B knobs of the conv kernels, process-wide (every handle of the process; the schedule is rebuilt): "tile" (default 1:
  *       large maps stage an 8 x 16 tile's input patch in LDS; 0: fragments straight from global memory), "splitk_max_m"
  *       (default 8192: maps up to this many pixels split K over the four waves of a workgroup), "xcd" (default 0: 1 / 2 remap the
- *       workgroup order so that an XCD owns an image band -- measured as no gain), "pool_lds" (default 1: SPPF's pools in LDS). */
+ *       workgroup order so that an XCD owns an image band -- measured as no gain), "pool_lds" (default 1: SPPF's pools in LDS), "wlds" (default 0: 1 stages the weight image of long-K
+ *       3x3 tiles in LDS too -- measured slower, 0.78 vs 0.74 ms: 96 KB of LDS leave one workgroup per CU). */
 int flope_yolo_set_option(flope_yolo_handle h, const char* name, int value);
 /* developer aid: `iters` forwards with a HIP event pair around every launch of the graph; writes a text table (mean
  * microseconds per launch, kind, geometry, state_dict name) into text_out[cap] */

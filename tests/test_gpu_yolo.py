@@ -103,13 +103,16 @@ def test_lds_tile_path_equals_the_global_fragment_path(ysd):
         img = synthetic_frame(11, H, W)
         y = _engine(ysd, H, W, imgsz)
         outs = []
-        for tile in (1, 0):
+        for tile, wlds in ((1, 1), (0, 1), (1, 0)):          # wlds: long-K 3x3 tiles keep their weight image in LDS as well
             y.set_option("tile", tile)
+            y.set_option("wlds", wlds)
             y.forward(img)
             outs.append([y.read_tensor(k).cpu().numpy() for k in ("0", "1", "2", "3", "4", "13", "16", "19", "22", "proto", "box0", "cls0", "coef0", "box2")])
         y.set_option("tile", 1)
-        for a, b in zip(*outs):
-            assert np.array_equal(a, b)
+        y.set_option("wlds", 1)
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a, b)
         # SPPF's three cascaded 5x5 max-pools: the LDS kernel (row / column passes) against the 13 x 13 ring sweep
         y.set_option("pool_lds", 0)
         y.forward(img)
