@@ -36,7 +36,7 @@ extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_stem_pool_init();
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
-                                      const void* w, const float* bias, void* out, int dtype, int persist_blocks, void* stream);
+                                      const void* w, const float* bias, void* out, int dtype, int persist_blocks, int regpool, void* stream);
 
 using namespace flope_host;
 
@@ -90,7 +90,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0;
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -494,6 +494,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
+  else if (!strcmp(name, "stem_regpool")) { prev = e->opt_stem_regpool; e->opt_stem_regpool = value != 0; return prev; }
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -598,8 +599,11 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
                                                    e->stem_bias, bp.ptr, dt,
                                                    // persistent form where it measured faster (r02, same-run A/B at B = 256): 224 x 224 crops
                                                    // +2.7 % on the step; 512 x 512 crops -7 % on the kernel.  1 = auto, 2 = always, 0 = never
-                                                   (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
-                                                   stream));
+                                                   // stem_regpool (r02, off): the register-pool kernel, three workgroups per CU -- measured slower
+                                                   // (197 vs 150 us at 224 x 224, 983 vs 697 us at 512 x 512: +30 % MFMAs for the duplicated rows)
+                                                   e->opt_stem_regpool ? 3 * e->num_cus
+                                                   : (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
+                                                   e->opt_stem_regpool, stream));
   } else {
     SMARK();
     K_TRY(e, "prep_input", flope_prep_input_launch(x, in_format, batch, e->H, e->W, stem_in, e->sHip, e->sWip, dt, stream));

@@ -210,6 +210,22 @@ def test_split_k_small_batches(state_dict, H, W, B):
     e.close()
 
 
+@pytest.mark.parametrize("H,W,B,dtype", [(224, 224, 5, "f16"), (200, 136, 3, "bf16"), (512, 512, 2, "f16")])
+def test_stem_register_pool_kernel_equals_the_lds_pool_kernels(state_dict, H, W, B, dtype):
+    """Option stem_regpool: 7 x 7 pooled pixels per workgroup, the max-pool on packed ReLU outputs in registers (v_pk_max
+    across three accumulator tiles, DPP row shifts across three lanes).  Same MFMA sequence per conv output: the pooled map
+    and everything behind it are identical to the default kernels', ragged sizes included."""
+    torch.manual_seed(B)
+    x = torch.rand(B, 3, H, W)
+    e = _engine(state_dict, H, W, B, dtype)
+    r9a, _ = _run(e, x)
+    pa = e.read_stage("pool", B).clone()
+    assert e.set_option("stem_regpool", 1) == 0
+    r9b, _ = _run(e, x)
+    assert torch.equal(pa, e.read_stage("pool", B)) and torch.equal(r9a, r9b)
+    e.close()
+
+
 @pytest.mark.parametrize("B", [1, 37, 256])
 def test_fc1_packed_weights_equal_the_row_major_kernel(state_dict, B):
     """fc.0 on pre-packed (A-fragment order) weights with LDS-staged feature rows runs the same MFMA sequence per output as
