@@ -56,6 +56,7 @@ SIGNATURES = {
     "flope_yolo_profile": (_I, [_P, _P, _I, C.c_char_p, _I, _P]),
     "flope_yolo_flops": (_D, [_P]),
     "flope_yolo_launches": (_I, [_P]),
+    "flope_yolo_graph_cache_size": (_I, [_P]),
     "flope_tf_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "flope_tf_destroy": (_I, [_P]),
     "flope_tf_last_error": (C.c_char_p, [_P]),

@@ -121,6 +121,9 @@ struct ConvP {
   // conv_stag row bands on maps wider than 64 columns: tiles are 8 rows x one of nseg 64-column segments
   // (tiles_per_image = Ho / 8 * nseg); 0 / 1 = full-width bands
   int nseg;
+  // conv_stag flat tiles: 1 = LDS patch rows at pitch W + 4 with the slot swizzle taken from i * W + c (conflict-free fragment
+  // reads across row wraps, r03); 0 = the r02 image (natural pitch)
+  int skew;
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

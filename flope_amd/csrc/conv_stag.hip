@@ -96,18 +96,36 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   // 64-column SEGMENT; its patch is 10 rows x 66 columns, stored in LDS at a pitch of kSegPitch pixels, and patch pixel
   // (pr, pc) comes from input pixel (R0 + pr, 64 s0 + pc) -- the per-lane source offsets below carry that mapping, the
   // LDS side does not change.
+  // Flat tiles (!ROWS, r03): the LDS image of the patch is NOT a copy of the padded rows.  A 16-pixel MFMA tile of a 28 / 14 /
+  // 7-wide map wraps one to three image rows; with the rows at their natural pitch (W + 2) and the slot swizzle taken from the
+  // LDS pixel index, the pixels behind a wrap land on bank quads the pixels before it already use (r02: SQ_LDS_BANK_CONFLICT =
+  // 29 % of SQ_LDS_IDX_ACTIVE on this kernel, 0 on the row-band and gather kernels).  A ds_read_b128 lane group holds 8 even
+  // pixels at k-slot g and 8 odd ones at g ^ 1; it is conflict-free iff the 16 (pixel mod 4, slot) pairs differ.  With
+  //     LDS pixel index  P(i, c) = i * (W + 4) + c          (patch row i, column c: the pitch is = W mod 4)
+  //     slot swizzle     s(i, c) = ((i * W + c) >> 2) & 3   (v = i * W + c advances by ONE per output pixel across a row wrap)
+  // tap (dy, dx) of output pixel k of a tile reads P = P0 + k (mod 4) and s = ((v0 + k) >> 2) & 3 for every k that stays inside one
+  // image: sixteen consecutive v give sixteen different (v mod 4, (v >> 2) mod 4) pairs, whatever the row wraps in between.  (A tile
+  // that also crosses an IMAGE boundary -- 2 / 8 / 33 % of the pixel tiles at 28 / 14 / 7-wide maps -- skips two border rows and keeps
+  // two-way conflicts behind the crossing.)  Both sides are per-lane tables already: DMA source offsets here, xoff[] below.
   constexpr int kSegPitch = 66;
   const bool seg = ROWS && p.nseg > 1;
-  const int pitch = seg ? kSegPitch : p.Wip;
+  const bool skew = !ROWS && p.skew;                       // p.skew = 0: the r02 image (natural pitch, swizzle from the LDS pixel index), A/B only
+  const int pitch = seg ? kSegPitch : (skew ? p.Wip + 2 : p.Wip);
   unsigned psrc[PT];
 #pragma unroll
   for (int rr = 0; rr < PT; ++rr) {
     const int q = rr * 512 + wave * 64 + lane;
-    const int pi = q >> 2, js = (q & 3) ^ ((pi >> 2) & 3);
+    const int pi = q >> 2;
+    int js = (q & 3) ^ ((pi >> 2) & 3);
     int spix = pi;                                         // source pixel, relative to the patch origin
     if (seg) {
       const int pc_ = min(pi, 10 * kSegPitch - 1), pr_ = pc_ / kSegPitch;
       spix = pr_ * p.Wip + (pc_ - pr_ * kSegPitch);
+    }
+    if (skew) {
+      const int pr_ = pi / pitch, pc_ = pi - pr_ * pitch;
+      spix = pr_ * p.Wip + min(pc_, p.Wip - 1);            // the two pad pixels of a row re-read its last pixel (never read back)
+      js = (q & 3) ^ (((pr_ * p.Wo + pc_) >> 2) & 3);
     }
     psrc[rr] = (unsigned)(spix * (int)pixB + js * 16);
   }
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #define LANE_SETUP()                                                                                           \
   do {                                                                                                         \
     _Pragma("unroll") for (int pt = 0; pt < (ROWS ? 1 : MT); ++pt) {                                           \
-      int pi0_;                                                                                                \
+      int pi0_, v0_ = 0;                                                                                       \
       if constexpr (ROWS) {                                                                                    \
         pi0_ = (group * 4 + wpx) * pitch + pcol;                                                               \
       } else {                                                                                                 \
@@ -162,11 +180,14 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
         const int m_ = min(mm_, mend - 1);                                                                     \
         const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - b_ * HoWo;                                     \
         const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;                                    \
-        pi0_ = (b_ * p.Hip + ho_ - R0) * p.Wip + wo_;                                                          \
+        const int i_ = b_ * p.Hip + ho_ - R0;                                                                  \
+        pi0_ = i_ * pitch + wo_;                                                                               \
+        v0_ = i_ * p.Wo + wo_;                                                                                 \
       }                                                                                                        \
       _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                          \
         const int pi = pi0_ + (t / 3) * pitch + (t % 3);                                                       \
-        xoff[t][pt] = (pi << 6) + ((g ^ ((pi >> 2) & 3)) << 4);                                                \
+        const int sv = skew ? v0_ + (t / 3) * p.Wo + (t % 3) : pi;                                             \
+        xoff[t][pt] = (pi << 6) + ((g ^ ((sv >> 2) & 3)) << 4);                                                \
       }                                                                                                        \
     }                                                                                                          \
   } while (0)

@@ -90,7 +90,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1;
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -206,7 +206,7 @@ void plan_conv(flope_engine* e, Conv& c) {
   if (e->opt_stag && c.k == 3 && c.stride == 1 && c.cin % 64 == 0 && (c.cout >= 128 || (c.cout == 64 && e->opt_stag >= 2))) {
     const int sbm = c.cout == 64 ? 512 : 256, sbn = c.cout == 64 ? 64 : 128;
     const int rows = patch_rows(c, B, sbm, false);
-    const long pieces = (long)rows * Wip * 4;
+    const long pieces = (long)rows * (Wip + (e->opt_skew ? 2 : 0)) * 4;   // skew: LDS row pitch W + 4, conflict-free fragment reads across row wraps (conv_stag.hip)
     int P = (int)((pieces + 511) / 512);
     if (P < 2) P = 2;                                  // kernel instantiations: 2..6 and 8 DMA rounds per patch burst
     if (P < 4 && c.cout >= 128 && e->opt_dsfuse) P = 4;  // 32 KB buffers: room for a folded shortcut's gathered pixel tiles
@@ -497,6 +497,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "stem_regpool")) { prev = e->opt_stem_regpool; e->opt_stem_regpool = value != 0; return prev; }
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
+  else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
@@ -648,6 +649,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       const int sbm = c.cout == 64 ? 512 : 256;
       p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + sbm - 1) / sbm; p.ntiles = c.cout == 64 ? 1 : c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
       p.total_tiles = p.mtiles * p.ntiles;
+      p.skew = e->opt_skew;
       if (c.ds_conv >= 0) {
         const Conv& cd = e->convs[c.ds_conv];
         p.res = nullptr; p.bias = c.bias_fused;

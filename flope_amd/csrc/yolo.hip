@@ -1513,9 +1513,11 @@ extern "C" int flope_ynms_launch(const YNmsP* p, void* stream) {
   return (int)hipGetLastError();
 }
 
+extern "C" int flope_y32_mask_low_launch(const YMaskP* p, void* stream);   // yolo_f32.hip: float32 proto map
 extern "C" int flope_ymask_launch(const YMaskP* p, int dtype, void* stream) {
   if (p->max_det < 1 || p->max_det > 300) return (int)hipErrorInvalidValue;
-  YDISPATCH(dtype, ymask_low_kernel, dim3((p->mh * p->mw + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  if (dtype == 2) { if (int s = flope_y32_mask_low_launch(p, stream)) return s; }
+  else YDISPATCH(dtype, ymask_low_kernel, dim3((p->mh * p->mw + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
   hipLaunchKernelGGL(ymask_merge_kernel, dim3((p->ih * p->iw + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
 }

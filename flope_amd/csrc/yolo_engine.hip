@@ -45,6 +45,14 @@ extern "C" int flope_ynms_launch(const YNmsP* p, void* stream);
 extern "C" int flope_ymask_launch(const YMaskP* p, int dtype, void* stream);
 extern "C" int flope_resize_linear_u8_launch(const uint8_t* in, int h, int w, uint8_t* out, int H, int W, void* stream);
 extern "C" int flope_yread_launch(const void* src, int is_f32, int H, int W, int C, int ld, int dtype, float* dst, void* stream);
+// strict float32 mode (yolo_f32.hip): the same graph on float32 maps, plain fused-multiply-add convolutions
+extern "C" int flope_y32_conv_launch(const YConvP* p, void* stream);
+extern "C" int flope_y32_dw_launch(const YDwP* p, void* stream);
+extern "C" int flope_y32_pool_launch(const YPoolP* p, void* stream);
+extern "C" int flope_y32_up_launch(const YUpP* p, void* stream);
+extern "C" int flope_y32_attn_init();
+extern "C" int flope_y32_attn_launch(const YAttnP* p, void* stream);
+extern "C" int flope_y32_letter_launch(const YLetterP* p, void* stream);
 
 using namespace flope_host;
 
@@ -101,7 +109,8 @@ struct flope_yolo {
   int opt_batch = 1;
   int opt_bneck = 1;                                          // 1: Bottleneck pairs as one fused launch (ybneck_kernel); 0: two conv launches
   int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
-  std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // captured detect sequences, most recently used last (<= kGraphCache)
+  struct Captured { GraphKey key; hipGraphExec_t exec; hipEvent_t done; };   // done: recorded behind the last replay
+  std::vector<Captured> graphs;                               // captured detect sequences, most recently used last (<= kGraphCache)
   double flops = 0.0;
   std::string err;
 };
@@ -126,6 +135,8 @@ struct Builder {
   int rc = 0;
   int n_pred = 0;                             // prediction-row column blocks written so far (each its own pseudo tensor)
   void push(Op& op) { e->ops.push_back(op); }
+  bool f32() const { return e->dtype == FLOPE_DT_F32; }
+  size_t esz() const { return f32() ? 4 : 2; }              // bytes per map element
   static Rng rng(const View& v) { return Rng{v.t, v.off, v.off + v.C}; }
 
   bool has(const std::string& k) const { return sd.count(k) != 0; }
@@ -156,14 +167,14 @@ struct Builder {
 
   int tensor(int H, int W, int C) {
     Tensor t; t.H = H; t.W = W; t.C = C;
-    const size_t bytes = (size_t)H * W * C * 2 + 256;
+    const size_t bytes = (size_t)H * W * C * esz() + 256;
     if (hipMalloc(&t.ptr, bytes) != hipSuccess || hipMemset(t.ptr, 0, bytes) != hipSuccess) { if (!rc) rc = yfail(e, FLOPE_EHIP, "hipMalloc (activation map) failed"); t.ptr = nullptr; }
     e->tensors.push_back(t);
     return (int)e->tensors.size() - 1;
   }
   View full(int t) { View v; v.t = t; v.off = 0; v.C = e->tensors[t].C; return v; }
   View slice(int t, int off, int C) { View v; v.t = t; v.off = off; v.C = C; return v; }
-  void* vptr(const View& v) { return (char*)e->tensors[v.t].ptr + (size_t)v.off * 2; }
+  void* vptr(const View& v) { return (char*)e->tensors[v.t].ptr + (size_t)v.off * esz(); }
   int vld(const View& v) { return e->tensors[v.t].C; }
   int vH(const View& v) { return e->tensors[v.t].H; }
   int vW(const View& v) { return e->tensors[v.t].W; }
@@ -180,6 +191,7 @@ struct Builder {
   }
   void tap(const std::string& name, const View& v) {
     Tap t; t.ptr = vptr(v); t.H = vH(v); t.W = vW(v); t.C = v.C; t.ld = vld(v);
+    t.is_f32 = f32() ? 1 : 0;
     e->taps[name] = t;
   }
 
@@ -188,6 +200,15 @@ struct Builder {
   // stored in MFMA A-fragment order [channel block][k step][channel tile][lane = kq * 16 + row][8 k]: a wave-load is 1 KiB
   void pack(const std::vector<float>& wf, const std::vector<float>& bf, int cout_, int cin, int cin_pad, int k, int nt,
             const void** w_dev, const float** b_dev, int* ksteps) {
+    if (f32()) {            // strict mode: float32 [rows][tap * cin_pad + ci], rows in channel order (yolo_f32.hip)
+      const int K = k * k * cin_pad;
+      std::vector<float> w((size_t)cout_ * K, 0.f);
+      for (int co = 0; co < cout_; ++co)
+        for (int tap = 0; tap < k * k; ++tap)
+          for (int ci = 0; ci < cin; ++ci) w[(size_t)co * K + tap * cin_pad + ci] = wf[((size_t)co * cin + ci) * k * k + tap];
+      *w_dev = upload(w); *b_dev = (const float*)upload(bf); *ksteps = (K + 31) / 32;
+      return;
+    }
     const int CB = 16 * nt, rows = (cout_ + CB - 1) / CB * CB, K = k * k * cin_pad, Kp = (K + 31) / 32 * 32;
     std::vector<uint16_t> w((size_t)rows * Kp, 0);
     std::vector<float> b(rows, 0.f);
@@ -340,7 +361,7 @@ struct Builder {
     if (rc || e->ops.size() < 2) return;
     const Op& o2 = e->ops.back();
     const Op& o1 = e->ops[e->ops.size() - 2];
-    if (o1.kind != Op::CONV || o2.kind != Op::CONV || !flope_ybneck_fusable(&o1.conv, o1.nt, &o2.conv, o2.nt)) return;
+    if (f32() || o1.kind != Op::CONV || o2.kind != Op::CONV || !flope_ybneck_fusable(&o1.conv, o1.nt, &o2.conv, o2.nt)) return;
     Op f; f.kind = Op::BNECK; f.name = p; f.conv = o1.conv; f.conv2 = o2.conv; f.nt = o1.nt; f.nt2 = o2.nt;
     f.reads = o1.reads;                                   // the intermediate map never leaves the workgroup
     for (const Rng& r : o2.reads)
@@ -393,6 +414,10 @@ struct Builder {
     for (int j = 0; j < n; ++j) {
       const std::string q = p + ".m." + std::to_string(j);
       const int qkv = tensor(H, W, cout(q + ".attn.qkv")), att = tensor(H, W, c), att2 = tensor(H, W, c), f = tensor(H, W, cout(q + ".ffn.0"));
+      if ((size_t)16 * H * W * sizeof(float) > 160 * 1024) {   // the generic attention kernel keeps 16 score rows in LDS
+        if (!rc) rc = yfail(e, FLOPE_EINVAL, "C2PSA attention: " + std::to_string(H * W) + " tokens at this frame size / imgsz exceed the supported 2560 (imgsz up to ~1600 for 16:9 frames)");
+        return;
+      }
       if (cout(q + ".attn.qkv") != heads * 128) { if (!rc) rc = yfail(e, FLOPE_EWEIGHTS, "unsupported attention layout at " + q); return; }
       conv(q + ".attn.qkv", b, full(qkv), 1, 0);
       Op op; op.kind = Op::ATTN; op.name = q + ".attn";
@@ -412,6 +437,16 @@ struct Builder {
 };
 
 int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
+  if (e->dtype == FLOPE_DT_F32) {
+    switch (op.kind) {
+      case Op::CONV: return flope_y32_conv_launch(&op.conv, st);
+      case Op::DW: return flope_y32_dw_launch(&op.dw, st);
+      case Op::POOL: return flope_y32_pool_launch(&op.pool, st);
+      case Op::UP: return flope_y32_up_launch(&op.up, st);
+      case Op::ATTN: return flope_y32_attn_launch(&op.attn, st);
+      case Op::BNECK: return (int)hipErrorInvalidValue;      // never built in this mode
+    }
+  }
   switch (op.kind) {
     case Op::CONV: return flope_yconv_launch(&op.conv, e->dtype, op.nt, st);
     case Op::DW: return flope_ydw_launch(&op.dw, e->dtype, st);
@@ -427,6 +462,9 @@ int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
   return (int)hipErrorInvalidValue;
 }
 
+// strict float32 mode runs the program-order schedule only (one launch per op of the ultralytics yaml)
+inline int sched_index(const flope_yolo* e) { return (e->opt_batch && e->dtype != FLOPE_DT_F32) ? 1 : 0; }
+
 int launch_one(flope_yolo* e, const Launch& L, hipStream_t st) {
   return L.op >= 0 ? launch_op(e, e->ops[L.op], st) : flope_ymulti_launch(&L.multi, L.multi_dev, e->dtype, st);
 }
@@ -440,7 +478,7 @@ std::string launch_name(const flope_yolo* e, const Launch& L) {
 
 int run_ops(flope_yolo* e, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  for (const Launch& L : e->sched[e->opt_batch ? 1 : 0]) {
+  for (const Launch& L : e->sched[sched_index(e)]) {
     const int s = launch_one(e, L, st);
     if (s != 0) return yfail(e, FLOPE_EHIP, launch_name(e, L) + ": " + hipGetErrorString((hipError_t)s));
   }
@@ -469,6 +507,7 @@ int build_schedules(flope_yolo* e) {
   }
   e->sched[0].clear(); e->sched[1].clear();
   for (int i = 0; i < n; ++i) { Launch L; L.op = i; e->sched[0].push_back(L); }
+  if (e->dtype == FLOPE_DT_F32) return FLOPE_OK;             // no batched grids in the strict mode
   for (int lv = 0; lv < depth; ++lv) {
     // one grid's dynamic LDS is that of its hungriest op, so a fused Bottleneck (up to 134 KB) leaves the plain convs it shares a
     // grid with one workgroup per CU -- measured, sharing still wins (0.741 vs 0.757 ms per frame: a launch less per level);
@@ -506,6 +545,16 @@ int build_schedules(flope_yolo* e) {
   return FLOPE_OK;
 }
 
+// a captured sequence may still be replaying on some stream: wait for the event recorded behind its last launch
+void drop_graph(flope_yolo::Captured& g) {
+  if (g.done) { hipEventSynchronize(g.done); hipEventDestroy(g.done); }
+  hipGraphExecDestroy(g.exec);
+}
+void drop_graphs(flope_yolo* e) {
+  for (auto& g : e->graphs) drop_graph(g);
+  e->graphs.clear();
+}
+
 }  // namespace
 
 // ====================================================================================================================
@@ -516,7 +565,7 @@ extern "C" int flope_yolo_create(int device_id, int frame_h, int frame_w, int im
   *out = nullptr;
   if (frame_h < 32 || frame_w < 32 || frame_h > 8192 || frame_w > 8192) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: frame size must be within 32..8192");
   if (imgsz < 32 || imgsz > 2560 || imgsz % 32) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: imgsz must be a multiple of 32 within 32..2560");
-  if (dtype != FLOPE_DT_BF16 && dtype != FLOPE_DT_F16) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: dtype must be FLOPE_DT_F16 or FLOPE_DT_BF16");
+  if (dtype != FLOPE_DT_BF16 && dtype != FLOPE_DT_F16 && dtype != FLOPE_DT_F32) return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: dtype must be FLOPE_DT_F16, FLOPE_DT_BF16 or FLOPE_DT_F32");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: no HIP device visible (the product path has no CPU fallback)");
@@ -530,7 +579,7 @@ extern "C" int flope_yolo_create(int device_id, int frame_h, int frame_w, int im
   e->top = (int)nearbyint(dh - 0.1); e->left = (int)nearbyint(dw - 0.1);
   e->h = e->nh + e->top + (int)nearbyint(dh + 0.1); e->w = e->nw + e->left + (int)nearbyint(dw + 0.1);
   if (e->h % 32 || e->w % 32) { delete e; return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: letterboxed size is not a multiple of 32"); }
-  if (hipSetDevice(device_id) != hipSuccess || flope_yattn_init() != 0) { delete e; return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: device setup failed"); }
+  if (hipSetDevice(device_id) != hipSuccess || flope_yattn_init() != 0 || flope_y32_attn_init() != 0) { delete e; return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: device setup failed"); }
   *out = e;
   return FLOPE_OK;
 }
@@ -539,7 +588,7 @@ extern "C" int flope_yolo_destroy(flope_yolo_handle e) {
   if (!e) return FLOPE_OK;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
-  for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
+  drop_graphs(e);
   for (Tensor& t : e->tensors) if (t.ptr) hipFree(t.ptr);
   for (void* p : e->owned) if (p) hipFree(p);
   delete e;
@@ -717,7 +766,7 @@ extern "C" int flope_yolo_forward(flope_yolo_handle e, const uint8_t* frame_dev,
   if (!frame_dev) return yfail(e, FLOPE_EINVAL, "flope_yolo_forward: frame_dev is NULL");
   Y_TRY(e, hipSetDevice(e->device));
   YLetterP L = e->letter; L.frame = frame_dev;
-  int s = flope_yletter_launch(&L, e->dtype, stream);
+  int s = e->dtype == FLOPE_DT_F32 ? flope_y32_letter_launch(&L, stream) : flope_yletter_launch(&L, e->dtype, stream);
   if (s) return yfail(e, FLOPE_EHIP, std::string("letterbox: ") + hipGetErrorString((hipError_t)s));
   return run_ops(e, stream);
 }
@@ -749,11 +798,14 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   if (!e->opt_graph) return detect_body(e, frame_dev, conf, iou, max_det, det_dev, count_dev, mask_dev, stream);
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  GraphKey key{frame_dev, det_dev, count_dev, mask_dev, conf, iou, max_det, e->opt_batch * 4 + e->opt_bneck, e->opt_generic_attn};
+  GraphKey key;
+  memset(&key, 0, sizeof key);                              // the struct has tail padding and is compared bytewise
+  key.frame = frame_dev; key.det = det_dev; key.count = count_dev; key.mask = mask_dev; key.conf = conf; key.iou = iou;
+  key.max_det = max_det; key.batch = e->opt_batch * 4 + e->opt_bneck; key.generic_attn = e->opt_generic_attn;
   hipGraphExec_t exec = nullptr;
   for (size_t i = 0; i < e->graphs.size(); ++i)
-    if (memcmp(&key, &e->graphs[i].first, sizeof key) == 0) {
-      exec = e->graphs[i].second;
+    if (memcmp(&key, &e->graphs[i].key, sizeof key) == 0) {
+      exec = e->graphs[i].exec;
       if (i + 1 != e->graphs.size()) std::rotate(e->graphs.begin() + i, e->graphs.begin() + i + 1, e->graphs.end());
       break;
     }
@@ -770,10 +822,14 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
     const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
     if (ei != hipSuccess) return yfail(e, FLOPE_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
-    if (e->graphs.size() >= kGraphCache) { hipGraphExecDestroy(e->graphs.front().second); e->graphs.erase(e->graphs.begin()); }
-    e->graphs.emplace_back(key, exec);
+    if (e->graphs.size() >= kGraphCache) { drop_graph(e->graphs.front()); e->graphs.erase(e->graphs.begin()); }
+    flope_yolo::Captured c;
+    memcpy(&c.key, &key, sizeof key); c.exec = exec; c.done = nullptr;
+    if (hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) c.done = nullptr;
+    e->graphs.push_back(c);
   }
   Y_TRY(e, hipGraphLaunch(exec, st));
+  if (e->graphs.back().done) Y_TRY(e, hipEventRecord(e->graphs.back().done, st));   // most recently used = last
   return FLOPE_OK;
 }
 
@@ -799,8 +855,7 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
                    : !strcmp(name, "wlds") ? flope_yconv_wlds_mode(value) : flope_yconv_splitk_max_m(value);
     if (e->loaded) {
       if (int rc = build_schedules(e)) return rc;
-      for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
-      e->graphs.clear();
+      drop_graphs(e);
     }
     return prev;
   }
@@ -809,8 +864,7 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
     const int prev = e->opt_bneck; e->opt_bneck = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (e->loaded && prev != e->opt_bneck) {
       if (int rc = build_schedules(e)) return rc;
-      for (auto& g : e->graphs) hipGraphExecDestroy(g.second);
-      e->graphs.clear();
+      drop_graphs(e);
     }
     return prev;
   }
@@ -826,7 +880,7 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
   if (!e->loaded) return yfail(e, FLOPE_ESTATE, "flope_yolo_profile before flope_yolo_load_weights");
   Y_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  const std::vector<Launch>& sched = e->sched[e->opt_batch ? 1 : 0];
+  const std::vector<Launch>& sched = e->sched[sched_index(e)];
   const size_t n = sched.size();
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& x : ev) Y_TRY(e, hipEventCreate(&x));
@@ -834,7 +888,7 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
   int rc = FLOPE_OK;
   for (int it = 0; it < iters + 1 && !rc; ++it) {
     YLetterP L = e->letter; L.frame = frame_dev;
-    int s = flope_yletter_launch(&L, e->dtype, stream);
+    int s = e->dtype == FLOPE_DT_F32 ? flope_y32_letter_launch(&L, stream) : flope_yletter_launch(&L, e->dtype, stream);
     for (size_t i = 0; i < n && !s; ++i) {
       hipEventRecord(ev[i], st);
       s = launch_one(e, sched[i], st);
@@ -872,5 +926,6 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
   return FLOPE_OK;
 }
 
+extern "C" int flope_yolo_graph_cache_size(flope_yolo_handle e) { return e ? (int)e->graphs.size() : 0; }
 extern "C" double flope_yolo_flops(flope_yolo_handle e) { return e ? e->flops : 0.0; }
-extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->sched[e->opt_batch ? 1 : 0].size() + 6 : 0; }   // + letterbox, decode, nms, 2 mask kernels, resize
+extern "C" int flope_yolo_launches(flope_yolo_handle e) { return e ? (int)e->sched[sched_index(e)].size() + 6 : 0; }   // + letterbox, decode, nms, 2 mask kernels, resize

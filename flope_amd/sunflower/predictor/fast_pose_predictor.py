@@ -118,7 +118,9 @@ class FastPosePredictor:
             self._detector = yolo_path
         else:
             from flope_amd.yolo import YoloSeg, load_yolo_checkpoint
-            sd, ck_imgsz = load_yolo_checkpoint(str(yolo_path))
+            # a `.pt` is the reference's own argument (`YOLO(yolo_path)`, :36, unpickles it): same trust, explicit by suffix;
+            # anything else must be a plain state_dict that the weights_only loader accepts
+            sd, ck_imgsz = load_yolo_checkpoint(str(yolo_path), allow_pickle=str(yolo_path).endswith(".pt"))
             # ultralytics predicts at the size the checkpoint was trained with (the reference's is `yolo11nseg_1280.pt`, :177)
             self._yolo_args = (sd, int(imgsz or ck_imgsz or 1280), yolo_dtype)
             self._yolo_more = []               # further detector instances of the pipelined loop, built on first use
@@ -173,6 +175,10 @@ class FastPosePredictor:
         NS = 2 * (nd + 1)                               # frames in flight: nd detecting, one in the pose stage, one being uploaded
         slots = [dict(frame=torch.empty((H, W, 3), dtype=torch.uint8, device=dev), out=self.yolo.new_outputs(), depth=None,
                       ready=None, pose_done=None, shape=None) for _ in range(NS)]
+        # the slot buffers were filled on the caller's stream: every side stream starts behind that fill
+        cur = torch.cuda.current_stream(dev)
+        for s_ in [s_io, s_pose] + s_det:
+            s_.wait_stream(cur)
         prev_graph = [d.set_option("graph", 1) for d in dets]
 
         def stage_detect(t, rgb, depth):

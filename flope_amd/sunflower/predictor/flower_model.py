@@ -116,17 +116,34 @@ class FlowerModel:
                 self.scores = np.hstack((self.scores, np.array([1])))
                 self.kfs.append(get_kalman_filter(meas[i]))
 
-    def add_data(self, rgb, depth, cam_pose, ignore=False):
-        if self.pose_predictor is None:
-            raise RuntimeError("FlowerModel: pass pose_predictor= (PosePredictor / FastPosePredictor)")
-        cam_posemat = cam_pose_to_matrix(cam_pose)
-        flower_pose_cam = self.pose_predictor.get_flower_poses(rgb, depth)
+    def add_poses(self, flower_pose_cam, cam_pose, ignore=False):
+        """flower_model.py:224-255 after the predictor call: camera-frame poses of one frame -> world frame -> tracker."""
         if flower_pose_cam is None:
             return None, None
-        flower_pose = pose_cam_to_world(flower_pose_cam, cam_posemat)
+        flower_pose = pose_cam_to_world(flower_pose_cam, cam_pose_to_matrix(cam_pose))
         if ignore:
             self.assign_meas_to_state(poses_to_measurements(flower_pose))
         return flower_pose_cam, flower_pose.astype(np.float32)
+
+    def add_data(self, rgb, depth, cam_pose, ignore=False):
+        if self.pose_predictor is None:
+            raise RuntimeError("FlowerModel: pass pose_predictor= (PosePredictor / FastPosePredictor)")
+        return self.add_poses(self.pose_predictor.get_flower_poses(rgb, depth), cam_pose, ignore)
+
+    def add_stream(self, frames, ignore=True, detectors=2):
+        """`add_data` over a stream of (rgb, depth, cam_pose) frames with the predictor's pipelined loop
+        (`FastPosePredictor.iter_flower_poses`: several frames in flight on the GPU, results in frame order) instead of one
+        blocking `get_flower_poses` per frame.  Same tracker updates in the same order as calling add_data frame by frame
+        (build-defined convenience: the reference's loop, scripts/live_pose.py:31-41, is sequential).  Yields add_data's
+        (poses in the camera frame, poses in the world frame) per frame."""
+        if self.pose_predictor is None:
+            raise RuntimeError("FlowerModel: pass pose_predictor= (PosePredictor / FastPosePredictor)")
+        frames = list(frames)
+        it = getattr(self.pose_predictor, "iter_flower_poses", None)
+        poses = it(((f[0], f[1]) for f in frames), detectors=detectors) if it is not None else \
+            (self.pose_predictor.get_flower_poses(f[0], f[1]) for f in frames)
+        for f, pose_cam in zip(frames, poses):
+            yield self.add_poses(pose_cam, f[2], ignore)
 
     def get_state(self):
         return self.state

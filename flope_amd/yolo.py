@@ -14,26 +14,31 @@ import torch
 
 from . import _lib
 
-_DT = {"f16": _lib.DT_F16, "bf16": _lib.DT_BF16}
+_DT = {"f16": _lib.DT_F16, "bf16": _lib.DT_BF16, "f32": _lib.DT_F32}   # f32: strict parity mode (yolo_f32.hip)
 MAX_DET = 300
 
 
-def load_yolo_checkpoint(path: str):
+def load_yolo_checkpoint(path: str, allow_pickle: bool = False):
     """-> (state_dict of float tensors, imgsz or None).
 
     Accepts a plain ``state_dict`` file (``torch.save(model.state_dict(), f)`` -- keys ``model.<i>. ...``; readable
-    with ``weights_only=True``; an optional ``imgsz`` entry carries the training size).  An ultralytics ``.pt`` is a
-    pickled model object: it can only be opened where ultralytics is installed, in which case its weights are taken
-    from it and still run on this build's kernels."""
+    with ``weights_only=True``, which executes nothing from the file; an optional ``imgsz`` entry carries the training
+    size).  An ultralytics ``.pt`` is a pickled model object: opening it EXECUTES code from the file, so that route is
+    taken only on request (``allow_pickle=True``) and only where ultralytics is installed; its weights then still run on
+    this build's kernels."""
+    import pickle
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as exc:                      # a pickled ultralytics model: needs the package that defines its classes
+    except pickle.UnpicklingError as exc:         # the safe loader refused the file: a pickled model object, or a hostile file
+        if not allow_pickle:
+            raise RuntimeError(
+                f"{path}: not a plain state_dict file (the weights_only loader refused it). Export the weights once on a "
+                "machine that has ultralytics: tools/export_yolo_state_dict.py <model.pt> <out.pth> -- or, for a file you "
+                "trust, pass allow_pickle=True where ultralytics is installed.") from exc
         try:
             from ultralytics import YOLO
         except ImportError:
-            raise RuntimeError(
-                f"{path}: not a plain state_dict file ({type(exc).__name__}) and ultralytics is not installed. Export the "
-                "weights once on a machine that has it: tools/export_yolo_state_dict.py <model.pt> <out.pth>") from exc
+            raise RuntimeError(f"{path}: a pickled ultralytics model needs ultralytics, which is not installed") from exc
         y = YOLO(path)
         sd = {k: v.detach().float().cpu() for k, v in y.model.state_dict().items()}
         imgsz = (getattr(y.model, "args", None) or {}).get("imgsz") if isinstance(getattr(y.model, "args", None), dict) else None
@@ -53,8 +58,9 @@ class YoloSeg:
         if not torch.cuda.is_available():
             raise RuntimeError("flope_amd: no HIP device visible; the product path has no CPU fallback")
         self.lib = _lib.load()
-        self.device = torch.device("cuda", torch.cuda.current_device() if device is None
-                                   else torch.device(device).index or 0)
+        idx = None if device is None else torch.device(device).index          # "cuda" without an index = the current device
+        self.device = torch.device("cuda", torch.cuda.current_device() if idx is None else idx)
+        self.dtype = dtype
         self.frame_h, self.frame_w, self.imgsz = int(frame_h), int(frame_w), int(imgsz)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -196,3 +202,6 @@ class YoloSeg:
 
     def launches(self) -> int:
         return int(self.lib.flope_yolo_launches(self.handle))
+
+    def graph_cache_size(self) -> int:
+        return int(self.lib.flope_yolo_graph_cache_size(self.handle))

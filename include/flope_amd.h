@@ -209,7 +209,11 @@ double flope_tf_forward_flops(flope_tf_handle h, int batch, int seq_len);
  * LetterBox(imgsz, auto, stride 32) + BGR->RGB + /255 -> yolo11-seg graph (Conv+BN+SiLU, C3k2, SPPF, C2PSA,
  * upsample/concat neck, Segment head) -> DFL decode -> NMS -> coef.proto masks cropped, upsampled, > 0.
  * One handle = one device, one frame size.  dtype FLOPE_DT_F16 / FLOPE_DT_BF16 (16-bit maps, fp32 accumulation,
- * fp32 head outputs / decode / NMS). */
+ * fp32 head outputs / decode / NMS), or FLOPE_DT_F32 = strict mode: float32 maps and plain float32 fused-multiply-add
+ * convolutions over the same graph in program order (no MFMA, no 16-bit rounding; ~50x slower) -- the arithmetic the
+ * reference runs ultralytics in (fast_pose_predictor.py:49), so that the INTEGER outputs of get_bbox_mask (int16 boxes,
+ * uint8 mask, :52-56) can be compared for equality with a float32 pipeline.  Frame size / imgsz combinations whose
+ * stride-32 map exceeds 2,560 tokens (imgsz above ~1600 for 16:9 frames) are rejected by flope_yolo_load_weights. */
 typedef struct flope_yolo* flope_yolo_handle;
 int flope_yolo_create(int device_id, int frame_h, int frame_w, int imgsz, int dtype, flope_yolo_handle* out);
 int flope_yolo_destroy(flope_yolo_handle h);
@@ -257,6 +261,7 @@ int flope_yolo_set_option(flope_yolo_handle h, const char* name, int value);
 int flope_yolo_profile(flope_yolo_handle h, const uint8_t* frame_dev, int iters, char* text_out, int cap, void* stream);
 double flope_yolo_flops(flope_yolo_handle h);      /* 2*MAC of one forward (convs + attention) */
 int flope_yolo_launches(flope_yolo_handle h);      /* kernel launches per flope_yolo_detect */
+int flope_yolo_graph_cache_size(flope_yolo_handle h);  /* captured launch sequences currently held ("graph" option; <= 8) */
 
 #ifdef __cplusplus
 }

@@ -218,9 +218,10 @@ def non_max_suppression(pred, nc, conf_thres=0.25, iou_thres=0.7, max_det=300, m
     return det.reshape(-1, 6 + NM), keep
 
 
-def process_mask(proto, coef, boxes, shape):
+def process_mask(proto, coef, boxes, shape, return_float=False):
     """ops.process_mask(protos [32,mh,mw], masks_in [n,32], bboxes [n,4] letterbox xyxy, shape (ih,iw), upsample=True)
-    -> float32 {0,1} [n, ih, iw]"""
+    -> float32 {0,1} [n, ih, iw]   (return_float: the interpolated values before the `> 0` threshold, for tests that
+    need to know how close to the threshold a pixel is)"""
     proto = torch.as_tensor(proto, dtype=torch.float32)
     c, mh, mw = proto.shape
     ih, iw = shape
@@ -235,7 +236,7 @@ def process_mask(proto, coef, boxes, shape):
     x1, y1, x2, y2 = (b[:, i, None, None] for i in range(4))
     m = m * ((r >= x1) * (r < x2) * (cc >= y1) * (cc < y2))
     m = F.interpolate(m[None], (ih, iw), mode="bilinear", align_corners=False)[0]
-    return (m > 0).float()
+    return m if return_float else (m > 0).float()
 
 
 def letterbox_geometry(h0, w0, imgsz=1280, stride=32):

@@ -98,6 +98,29 @@ def test_layer1_row_band_kernel_every_stage(state_dict, H, W, B, streams):
     e.close()
 
 
+@pytest.mark.parametrize("H,W,B,dtype", [(224, 224, 19, "f16"), (224, 224, 3, "bf16"), (200, 136, 7, "f16"), (512, 512, 2, "f16"), (96, 80, 5, "f16")])
+def test_conflict_free_patch_image_does_not_change_a_bit(state_dict, H, W, B, dtype):
+    """conv_stag flat tiles (layers 2-4), r03: the LDS image of the input patch has row pitch W + 4 and takes its slot swizzle
+    from i * W + c (option skew = 1, default) so that fragment reads stay conflict-free across the row wraps of 28 / 14 / 7-wide
+    maps.  Only WHERE a pixel sits in LDS changes: every MFMA sees the same operands in the same order as with the r02 image
+    (skew = 0), so every stage and the rotations are bit-identical -- on even and odd map widths (25 / 13 / 7 at 200 x 136: odd
+    widths, ragged last tiles), with image-boundary crossings inside pixel tiles, with the folded shortcut and with split-K."""
+    torch.manual_seed(21)
+    x = torch.rand(B, 3, H, W)
+    outs = []
+    for skew in (1, 0):
+        e = _engine(state_dict, H, W, B, dtype, skew=skew)
+        r9, R = _run(e, x)
+        outs.append([r9, R] + [e.read_stage(s, B).cpu() for s in STAGES if s != "stem"])
+        plan = e.describe_plan()
+        e.close()
+    assert "conv_stag 256x128" in plan
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    emu = O.forward_stages_emulated(state_dict, x, TDT[dtype])
+    assert _rel(outs[0][0], emu["r9"]) <= (2e-3 if dtype == "f16" else 1e-2)
+
+
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
 def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg):
     """BASELINE cfg1 inputs (16 seeded 224x224 crops) against the committed goldens."""
@@ -638,3 +661,68 @@ def test_engine_on_the_second_device_while_the_first_is_current(state_dict):
     ref = O.procrustes_to_rotmat(O.forward(state_dict, x))
     assert R.device.index == 1 and (R.cpu() - ref).abs().max() <= 1e-3
     e.close()
+
+
+def test_multi_frame_fusion_on_the_device_path_vs_the_oracle_pipeline(state_dict, tmp_path):
+    """SURVEY N3 on the device path: a synthetic multi-frame stream with camera poses goes through
+    `FastPosePredictor.iter_flower_poses` (pipelined, built-in detector in strict float32 so that its integer boxes equal the
+    oracle detector's) into `FlowerModel` (flower_model.py:146-255: cam -> world, 50 mm association, 7-state Kalman tracks) and
+    is compared with `oracle/fusion_ref.py` fed by the ALL-oracle pipeline (oracle detector, crops, PoseResNet, Procrustes,
+    depth lift; scipy quaternions): same tracks, same hit counts, filtered states within the pose tolerances."""
+    import yaml
+    from scipy.spatial.transform import Rotation as Rot
+    from flope_amd.yolo_weights import synthetic_frame, synthetic_yolo_state_dict
+    from oracle import fusion_ref as F
+    from oracle import pipeline_ref as P
+    from oracle import yolo_ref as Y
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor
+    from sunflower.predictor.flower_model import FlowerModel
+    ysd = synthetic_yolo_state_dict(0)
+    H, W, imgsz = 1080, 1920, 1280                     # BASELINE configs[2] frame size: a dozen flowers per frame
+    yolo_f, ckpt, intr = tmp_path / "yolo.pth", tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save({**ysd, "imgsz": torch.tensor(imgsz)}, yolo_f)
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=1400.0, fy=1400.0, cx=W / 2, cy=H / 2, h=H, w=W)))
+    K = np.array([[1400.0, 0, W / 2], [0, 1400.0, H / 2], [0, 0, 1]])
+    pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr), yolo_dtype="f32")
+    rng = np.random.default_rng(11)
+    base = synthetic_frame(7, H, W)
+    frames = []
+    for i in range(5):                    # the same scene seen again (tracks get several hits), one different scene, one empty frame
+        img = base.copy() if i != 3 else synthetic_frame(6, H, W)
+        if i == 2:
+            img = np.zeros_like(img)
+        img[:4, :4] = rng.integers(0, 255, (4, 4, 3), dtype=np.uint8)      # frames are not byte-identical
+        depth = (400 + rng.normal(0, 1.5, (H, W))).astype(np.uint16)
+        cam = np.concatenate([rng.normal(0, 0.002, 3), Rot.from_rotvec(rng.normal(0, 0.002, 3)).as_quat()])
+        frames.append((img, depth, cam))
+    fm = FlowerModel(dist_th=50, pose_predictor=pred)
+    outs = list(fm.add_stream(frames, ignore=True, detectors=2))
+    assert len(outs) == 5 and outs[2] == (None, None)
+    # ---- all-oracle side
+    meas = []
+    for (img, depth, cam), (pc, pw) in zip(frames, outs):
+        rb, rmask = Y.get_bbox_mask(ysd, img, imgsz)
+        ref = P.get_flower_poses(lambda b: O.forward(state_dict, b), O.procrustes_to_rotmat, img, depth, rb, rmask, K) if rb.shape[0] else None
+        assert (ref is None) == (pc is None)
+        if ref is None:
+            continue
+        assert pc.shape == ref.shape
+        assert np.abs(pc[:, :3, :3] - ref[:, :3, :3]).max() <= 1e-3 and np.linalg.norm(pc[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
+        M = np.eye(4); M[:3, :3] = Rot.from_quat(cam[3:]).as_matrix(); M[:3, 3] = cam[:3]
+        world = np.einsum("ij,njk->nik", M, ref)                 # mvg.py:416-421
+        assert np.abs(pw - world).max() <= 2e-3
+        meas.append([list(np.concatenate([w[:3, 3], Rot.from_matrix(w[:3, :3]).as_quat()])) for w in world])
+    tracks = F.associate(meas, th=0.05)
+    assert len(fm.kfs) == len(tracks) and list(fm.scores) == [len(t) for t in tracks]
+    assert len(meas[0]) >= 5 and max(len(t) for t in tracks) >= 3 and len(tracks) > len(meas[0])   # re-observed tracks and newcomers both occur
+    for kf, t in zip(fm.kfs, tracks):
+        x, p = F.scalar_track(t)
+        assert np.abs(kf.x[:3] - np.array(x[:3])).max() <= 1e-5
+        assert np.abs(kf.x[3:] - np.array(x[3:])).max() <= 1e-3      # quaternion of a rotation known to 1e-3
+        assert np.allclose(np.diag(kf.P), p, atol=1e-12)
+    # frame by frame through add_data (sequential get_flower_poses): the identical tracker
+    fm2 = FlowerModel(dist_th=50, pose_predictor=pred)
+    for img, depth, cam in frames:
+        fm2.add_data(img, depth, cam, ignore=True)
+    assert len(fm2.kfs) == len(fm.kfs) and np.array_equal(fm2.filtered_state(), fm.filtered_state())

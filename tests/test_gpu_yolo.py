@@ -381,3 +381,146 @@ def test_yolo_error_paths(ysd):
     with pytest.raises(RuntimeError, match="already loaded"):
         y.load_state_dict(ysd)
     y.close()
+
+
+# ---- strict float32 mode (FLOPE_DT_F32, yolo_f32.hip): the integer outputs of get_bbox_mask against the all-float32 oracle --------
+def _oracle_detect(ysd, img, imgsz, conf=0.25, iou=0.7):
+    """the oracle's whole detector with its intermediate values: -> dict(o, pred, det, idx, boxes float32 frame xyxy,
+    bbox int16, mask_lb uint8 letterboxed, mask uint8 frame, mfloat = interpolated instance masks before `> 0`)"""
+    H, W = img.shape[:2]
+    x = Y.preprocess(img, imgsz)
+    o = Y.forward_layers(ysd, x)
+    nc = o["cls0"].shape[1]
+    pred = Y.decode(o).numpy()
+    det, idx = Y.non_max_suppression(pred, nc, conf, iou)
+    shape = tuple(x.shape[2:])
+    mfloat = Y.process_mask(o["proto"][0], det[:, 6:], det[:, :4], shape, return_float=True).numpy()
+    masks = (mfloat > 0).astype(np.float32)
+    boxes = Y.scale_boxes(shape, det[:, :4], img.shape)
+    return dict(o=o, pred=pred, det=det, idx=idx, boxes=boxes, bbox=boxes.astype(np.int16), mfloat=mfloat,
+                mask_lb=(np.clip(masks.sum(0), 0, 1) * 255).astype(np.uint8), mask=P.merge_masks(masks, (W, H)), shape=shape)
+
+
+def _assert_integer_outputs_equal(y, img, ref, tag, conf=0.25):
+    """bbox int16 and mask uint8 of the strict float32 device mode against the oracle's: EQUAL, except -- listed and
+    bounded -- where the oracle's own float32 value sits within float32 round-off of the decision boundary (a box
+    coordinate within 2e-3 px of an integer, an interpolated mask value within 1e-5 of zero)."""
+    H, W = img.shape[:2]
+    boxes, conf, cls, anchor, mask = y.detect(img, conf)
+    assert anchor.tolist() == ref["idx"].tolist(), (tag, anchor.tolist(), ref["idx"].tolist())
+    bb = boxes.astype(np.int16)                                  # fast_pose_predictor.py:55-56
+    np.testing.assert_allclose(boxes, ref["boxes"], atol=5e-3)
+    np.testing.assert_allclose(conf, ref["det"][:, 4], rtol=2e-5)
+    flips = np.argwhere(bb != ref["bbox"])
+    for i, c in flips:                                           # allowed only on a truncation boundary of the ORACLE's value
+        v = float(ref["boxes"][i, c])
+        assert abs(v - round(v)) < 2e-3 and abs(int(bb[i, c]) - int(ref["bbox"][i, c])) == 1, (tag, i, c, v, bb[i, c])
+    assert len(flips) <= 1, (tag, flips.tolist())
+    got_lb = y.read_tensor("mask_lb").cpu().numpy()[0].astype(np.uint8)
+    diff_lb = np.argwhere(got_lb != ref["mask_lb"])
+    for yy, xx in diff_lb:                                       # allowed only where an instance's interpolated value is ~0
+        assert np.abs(ref["mfloat"][:, yy, xx]).min() < 1e-5, (tag, yy, xx, ref["mfloat"][:, yy, xx])
+    assert len(diff_lb) <= 4, (tag, len(diff_lb))
+    if len(diff_lb) == 0:
+        assert np.array_equal(mask, ref["mask"]), tag            # uint8 frame mask: bit-exact
+    else:                                                        # a flipped letterbox pixel reaches at most its bilinear footprint
+        sy, sx = H / got_lb.shape[0], W / got_lb.shape[1]
+        bad = np.argwhere(mask != ref["mask"])
+        for yy, xx in bad:
+            assert min(abs(yy - (a + 0.5) * sy) + abs(xx - (b + 0.5) * sx) for a, b in diff_lb) <= 2 * (sy + sx) + 2, (tag, yy, xx)
+    return bb, mask, len(flips), len(diff_lb)
+
+
+@pytest.mark.parametrize("H,W,imgsz,seed,conf", [(1080, 1920, 1280, 6, 0.25), (360, 640, 640, 4, 0.05), (300, 500, 320, 3, 0.03)])
+def test_f32_strict_mode_integer_outputs_equal_the_fp32_oracle(ysd, H, W, imgsz, seed, conf):
+    """VERDICT r2 item 1 / north_star bar (1): the reference runs ultralytics in float32 and hands INTEGER boxes and a uint8
+    mask to the pose path (fast_pose_predictor.py:49-56).  In FLOPE_DT_F32 mode (float32 maps, plain float32 FMA convolutions,
+    same graph) every graph output is within float32 round-off of the oracle, NMS keeps the same anchors in the same order,
+    and `bbox.astype(int16)` / the uint8 mask are EQUAL to the oracle's."""
+    from flope_amd.yolo_weights import synthetic_frame
+    img = synthetic_frame(seed, H, W)
+    y = _engine(ysd, H, W, imgsz, "f32")
+    y.forward(img)
+    x = Y.preprocess(img, imgsz)
+    got_in = y.read_tensor("input").cpu()
+    assert torch.equal(got_in[:3], x[0]) and not got_in[3:].any()          # letterbox + BGR->RGB + /255 in float32: exact
+    ref = _oracle_detect(ysd, img, imgsz, conf)
+    o = ref["o"]
+    worst = 0.0
+    for name in LAYERS:
+        got = y.read_tensor(name).cpu()
+        assert got.shape == o[int(name)][0].shape, name
+        worst = max(worst, _rel(got, o[int(name)][0]))
+        assert _rel(got, o[int(name)][0]) <= 2e-5, (name, _rel(got, o[int(name)][0]))
+    for name in ["proto_up", "proto"] + [f"{k}{i}" for i in range(3) for k in ("box", "cls", "coef")]:
+        assert _rel(y.read_tensor(name).cpu(), o[name][0]) <= 2e-5, (name, _rel(y.read_tensor(name).cpu(), o[name][0]))
+    bb, mask, nflip, npix = _assert_integer_outputs_equal(y, img, ref, f"{H}x{W}", conf)
+    assert bb.shape[0] >= 3 and bb.dtype == np.int16 and mask.dtype == np.uint8
+    print(f"f32 strict {H}x{W}: worst graph rel-L2 {worst:.2e}, {bb.shape[0]} boxes, {nflip} boundary coordinates, {npix} threshold pixels")
+    # the 16-bit modes cannot be told apart from this one by their schedule options: batch / bneck are ignored here
+    y.set_option("batch", 1)
+    b2 = y.detect(img, conf)[0].astype(np.int16)
+    assert np.array_equal(b2, bb)
+    import ctypes as C
+    from flope_amd import _lib
+    h = C.c_void_p()
+    assert _lib.load().flope_yolo_create(0, H, W, imgsz, 7, C.byref(h)) != 0 and b"dtype" in _lib.load().flope_yolo_last_error(None)
+    y.close()
+
+
+def test_f32_frame_to_poses_equals_the_all_oracle_pipeline(ysd, state_dict, tmp_path):
+    """frame -> [N,4,4] through FastPosePredictor with the strict float32 detector, against a pipeline in which EVERYTHING is
+    the oracle (oracle boxes, oracle mask, oracle crops / PoseResNet / Procrustes / depth lift): the same flowers in the same
+    order, R within 1e-3, xyz within 1e-5 m.  (The 16-bit detector test above feeds the pose oracle the device's own boxes.)"""
+    import yaml
+    from flope_amd.yolo_weights import synthetic_frame
+    from oracle import posenet_ref as O
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor
+    H, W = 1080, 1920
+    img = synthetic_frame(7, H, W)
+    rng = np.random.default_rng(7)
+    depth = (400 + rng.normal(0, 4, (H, W))).astype(np.uint16)
+    yolo_f, ckpt, intr = tmp_path / "yolo11n_seg.pth", tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save({**ysd, "imgsz": torch.tensor(1280)}, yolo_f)
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=1400.0, fy=1400.0, cx=W / 2, cy=H / 2, h=H, w=W)))
+    pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr), yolo_dtype="f32")
+    rb, rmask = Y.get_bbox_mask(ysd, img, 1280)
+    bb, mask = pred.get_bbox_mask(img)
+    assert np.array_equal(bb, rb) and np.array_equal(mask, rmask)           # integer outputs: equal (seed chosen off any boundary)
+    Rt = pred.get_flower_poses(img, depth)
+    K = np.array([[1400.0, 0, W / 2], [0, 1400.0, H / 2], [0, 0, 1]])
+    ref = P.get_flower_poses(lambda b: O.forward(state_dict, b), O.procrustes_to_rotmat, img, depth, rb, rmask, K)
+    assert Rt is not None and Rt.shape == ref.shape and Rt.shape[0] >= 3
+    assert np.abs(Rt[:, :3, :3] - ref[:, :3, :3]).max() <= 1e-3
+    assert np.linalg.norm(Rt[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
+    assert np.array_equal(Rt[:, 3], np.tile([0, 0, 0, 1.0], (Rt.shape[0], 1)))
+
+
+def test_graph_cache_holds_one_entry_per_output_set(ysd):
+    """"graph" option: repeated detects with the same (frame, thresholds, outputs) tuple replay ONE captured sequence -- the
+    cache key is compared bytewise, so it must not depend on struct padding -- and more output sets than cache
+    slots evict the oldest entry only after its last replay has finished."""
+    from flope_amd.yolo_weights import synthetic_frame
+    img = synthetic_frame(13, 360, 640)
+    y = _engine(ysd, 360, 640, 640)
+    y.set_option("graph", 1)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ref = y.detect(img, 0.05)
+        for _ in range(5):
+            got = y.detect(img, 0.05)
+            assert y.graph_cache_size() == 1
+        outs = [y.new_outputs() for _ in range(11)]
+        frame = torch.from_numpy(img).cuda()
+        for k in range(3):
+            for o in outs:
+                y.detect_device(frame, 0.05, out=o, in_place=True)
+            assert y.graph_cache_size() == 8
+        st.synchronize()
+        for o in outs:
+            n = int(o[1].item())
+            assert n == len(ref[0]) and np.array_equal(o[0][:n, :4].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[4])
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    y.close()

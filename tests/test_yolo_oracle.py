@@ -97,6 +97,10 @@ def test_get_bbox_mask_contract(ysd):
     assert bb0.shape == (0, 4) and not mask0.any()
 
 
+class _NotATensor:
+    """stands in for the model object of an ultralytics .pt: a class the weights_only unpickler does not know"""
+
+
 def test_synthetic_checkpoint_key_set(ysd, tmp_path):
     """ultralytics naming: `model.<i>.` prefixes, Conv = .conv/.bn, plain head convs = .weight/.bias, DFL buffer."""
     keys = set(ysd)
@@ -113,4 +117,8 @@ def test_synthetic_checkpoint_key_set(ysd, tmp_path):
     assert imgsz == 640 and set(sd) == keys
     torch.save({"not": "a model"}, f)
     with pytest.raises(RuntimeError, match="state_dict"):
+        load_yolo_checkpoint(str(f))
+    # a pickled object (what an ultralytics .pt is) is refused by the safe loader and NOT escalated to a code-executing unpickle
+    torch.save({"model": _NotATensor()}, f)
+    with pytest.raises(RuntimeError, match="allow_pickle"):
         load_yolo_checkpoint(str(f))
