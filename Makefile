@@ -24,7 +24,17 @@ $(LIB): $(OBJS)
 $(HARNESS): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack.h
 	g++ -O2 -fPIC -shared -std=c++17 -I$(CSRC) -o $@ $<
 
+# diagnostic build (ablation bits + in-kernel clock stamps of conv_stag; results of dbg options are wrong by construction):
+#   make dbg && FLOPE_AMD_LIB=build/dbg/libflope_amd_dbg.so python tools/clock_probe.py
+DBGDIR   := build/dbg
+DBGOBJS  := $(patsubst $(CSRC)/%.hip,$(DBGDIR)/%.o,$(SRCS))
+$(DBGDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(DBGDIR)
+	$(HIPCC) $(HIPFLAGS) -DFLOPE_STAG_DBG -c $< -o $@
+dbg: $(DBGOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(DBGDIR)/libflope_amd_dbg.so $(DBGOBJS)
+
 clean:
 	rm -rf build $(LIB) $(HARNESS)
 
-.PHONY: all clean
+.PHONY: all clean dbg

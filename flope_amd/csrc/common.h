@@ -124,6 +124,11 @@ struct ConvP {
   // conv_stag flat tiles: 1 = LDS patch rows at pitch W + 4 with the slot swizzle taken from i * W + c (conflict-free fragment
   // reads across row wraps, r03); 0 = the r02 image (natural pitch)
   int skew;
+  // conv_stag flat 256 x 128 tiles with a residual input, one tile per workgroup: the residual arrives by LDS-DMA in the slots the
+  // last body's look-ahead DMAs leave unused (conv_stag.hip) instead of register loads in front of the first tile
+  int res_lds;
+  int prio;            // conv_stag: 1 = s_setprio 1 for waves 4..7, 2 = for waves 0..3, 0 = none
+  int dbg_lds_off;     // diagnostic builds, dbg & 128: LDS byte offset of the stamp area (behind the kernel's own image)
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

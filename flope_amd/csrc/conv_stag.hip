@@ -137,9 +137,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   // this lane's channels: two runs of 8 (host_pack.h stag_row_to_channel): cb .. cb + 7 (accumulator tiles 0, 1) and
   // cb + 32 .. cb + 39 (tiles 2, 3) -- byte offsets 16 g and 64 + 16 g inside the wave's 128-byte channel block
   const int cb = ntile * BN + wch * 64 + g * 8;
-  float bias[NT * 4];
-#pragma unroll
-  for (int i = 0; i < NT * 4; ++i) bias[i] = p.bias[cb + (i >> 3) * 32 + (i & 7)];
+  // folded-BN bias of accumulator tile ct: channels cb + (ct >> 1) * 32 + (ct & 1) * 4 .. + 3.  Read again at every tile boundary
+  // instead of living in 16 VGPRs for the life of the workgroup: the main loop runs at the 256-register limit (r03)
+  const float* const bias_p = p.bias + cb;
+#define BIAS4(ct_) (*(const f32x4*)(bias_p + ((ct_) >> 1) * 32 + ((ct_) & 1) * 4))
 
   // ---- tile geometry: wave-uniform part (first pixel, patch origin) and per-lane part (xoff, output offsets)
   int m0, mend, R0, mc0 = 0;                               // current tile (mc0: first output column, ROWS segments)
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
+    for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = BIAS4(ct);
   if (KSP > 1) {                                           // partial sums: the finalize kernel adds the bias once
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt)
@@ -277,9 +278,23 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   // folded into the accumulators while the first patch / weight tiles are still in flight -- with one workgroup
   // per CU nothing else would hide that latency at the kernel's tail.  Later tiles of a persistent grid load
   // theirs in the epilogue.
-  bool res_pre = RES;
+  // r03, RES on flat 256 x 128 tiles with one tile per workgroup (p.res_lds): the residual does not go through registers at all.
+  // Loaded up front it sat in front of the first patch / weight tiles -- every workgroup of a round asking for its 64 KB at the same
+  // moment, 4-6 us per round on the 28 x 28 maps (layer2.1.conv2 116 us against 92 us for the same conv without residual) -- and
+  // there are no 32 spare VGPRs to fetch it late.  But the last body of a tile issues 64 KB of LDS-DMA that nobody reads: the patch
+  // burst of double step 5 (the NEXT tile's first patch) and the two double tiles that wrap to the start of the weight panel
+  // (double steps 7 and 8).  Those exact slots (patch buffer 0: rounds 0..3; ring slots 0 and 1: two rounds each) now receive the
+  // tile's residual, lane (wave, l) fetching with round r = 2 pt + c the 16 bytes it will itself add in the epilogue -- no other
+  // wave reads them, so the wave's own vmcnt(0) orders the read-back, and every counted wait of the main loop stays as it was.
+  const bool res_lds = RES && !ROWS && BN == 128 && PT >= 4 && p.res_lds;
+  bool res_pre = RES && !res_lds;
+  unsigned roff[(RES && !ROWS) ? MT : 1];                  // res_lds: 32-bit byte offsets of this lane's residual / output pixels
+  if constexpr (RES && !ROWS) if (res_lds) {               // (computed once: four registers, not four fastdiv chains inside the loop)
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) { bool v_; roff[pt] = (unsigned)out_off(pt, v_); }
+  }
   u32x4 rpre[RES ? MT : 1][2];
-  if constexpr (RES) {
+  if constexpr (RES) if (!res_lds) {
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
       bool v_;
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     ISSUE_DT(1, 1);
     WAIT_VM(TG);                               // patch 0 and double tile 0 landed (double tile 1 may fly)
   }
-  if constexpr (RES) {
+  if constexpr (RES) if (!res_lds) {
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
@@ -359,6 +374,9 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     }
   }
   if (group == 1) BARRIER();                   // group B runs one phase behind group A
+  // static priority for one half of the workgroup (MI355X_MICROARCH "two waves per SIMD", item 4): the later-dispatched half loses
+  // the VALU arbitration on every segment; p.prio 1 raises waves 4..7, 2 raises waves 0..3, 0 leaves both at 0 (A/B option)
+  if (p.prio == 1 + (1 - group)) __builtin_amdgcn_s_setprio(1);
 
   // Every wave executes the SAME stream per double step D (two (half-chunk, tap) pairs u = 2D, 2D+1 of the
   // 18 that make up two half-chunks), no group tests inside the loop:
@@ -383,6 +401,26 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
 #else
   constexpr int dbg = 0;
 #endif
+#ifdef FLOPE_STAG_DBG
+  // dbg & 128: four shader-clock stamps per double step (start / before barrier 1 / after barrier 1 / after the MFMAs were issued) of
+  // the first kStampD double steps, wave 0 of each group, parked in LDS behind the kernel's own image (the host adds 2 KB of dynamic
+  // LDS in this mode) and copied out after the loop: records of 4 x uint64 at p.split_ws + 64 KB + ((block * 2 + group) * kStampD + d) * 32 B
+  constexpr int kStampD = 27;
+  int st_n = 0;
+  bool st_done = false;
+  char* const st_lds = smem + p.dbg_lds_off + group * (kStampD * 32);
+#define STAMP(k_)                                                                                              \
+  do {                                                                                                         \
+    if ((dbg & 128) && wl == 0 && st_n < kStampD) {                                                            \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+      if (lane == 0) *(unsigned long long*)(st_lds + st_n * 32 + (k_) * 8) = t_;                               \
+    }                                                                                                          \
+  } while (0)
+#define STAMP_NEXT() do { if (st_n < kStampD) ++st_n; } while (0)
+#else
+#define STAMP(k_) do {} while (0)
+#define STAMP_NEXT() do {} while (0)
+#endif
   u32x4 rq[(RES && ROWS) ? MT : 1][2];                      // ROWS + RES: next tile's residual, in flight from double step 6
   int dn = 2;                                               // double tile to issue at the start of the next double step
   int hc = 2 * body0;                                       // first half-chunk of the current body
@@ -394,15 +432,36 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     constexpr int U0_ = 2 * (D), U1_ = 2 * (D) + 1;                                                            \
     constexpr int WN_ = TG + (((D) == 0 || (D) == 1 || (D) == 5 || (D) == 6) ? PT : 0) +                       \
                         ((RES && ROWS && ((D) == 6 || (D) == 7)) ? 2 * MT : 0);                                \
+    STAMP(0);                                                                                                  \
+    const bool rl_ = RES && !ROWS && BN == 128 && PT >= 4 && res_lds && hc + 2 >= hc_end;   /* last body: residual rides in the idle slots */ \
     if (!WRES && !(dbg & 1)) {                                                                                 \
-      const int di_ = dn < ND ? dn : dn - ND;                                                                  \
-      ISSUE_DT(di_, ((D) + 2) % NBD);                                                                          \
+      if (RES && !ROWS && BN == 128 && PT >= 4 && ((D) == 7 || (D) == 8) && rl_) {                             \
+        unsigned ro_ = roff[(RES && !ROWS) ? (D) - 5 : 0];                                                     \
+        asm volatile("" : "+v"(ro_));          /* keep the 32-bit offset live, not a hoisted 64-bit address (spills) */ \
+        const char* rp_ = (const char*)p.res + ro_;                                                            \
+        _Pragma("unroll") for (int o = 0; o < TG; ++o)                                                         \
+          GLDS16(rp_ + o * 64, Bs + (((D) + 2) % NBD) * DT_B + o * 8192 + wave * 1024);                        \
+      } else {                                                                                                 \
+        const int di_ = dn < ND ? dn : dn - ND;                                                                \
+        ISSUE_DT(di_, ((D) + 2) % NBD);                                                                        \
+      }                                                                                                        \
     }                                                                                                          \
     ++dn;                                                                                                      \
     if ((D) == 0 && !(dbg & 2)) ISSUE_PATCH(patch_src + (hc + 1) * 64, 1);                                     \
     if ((D) == 5 && !(dbg & 2)) {                                                                              \
-      const char* s_ = hc + 2 < hc_end ? patch_src + (hc + 2) * 64 : (has_next ? n_patch_src : patch_src);     \
-      ISSUE_PATCH(s_, 0);                                                                                      \
+      if (RES && !ROWS && BN == 128 && PT >= 4 && rl_) {                                                       \
+        _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {                                                     \
+          unsigned ro_ = roff[(RES && !ROWS) ? pt : 0];                                                        \
+          asm volatile("" : "+v"(ro_));                                                                        \
+          const char* rp_ = (const char*)p.res + ro_;                                                          \
+          _Pragma("unroll") for (int c = 0; c < 2; ++c) GLDS16(rp_ + c * 64, Ps + ((pt * 2 + c) * 512 + wave * 64) * 16); \
+        }                                                                                                      \
+        _Pragma("unroll") for (int rr = 4; rr < PT; ++rr)       /* keeps the op count of a patch burst */      \
+          GLDS16(patch_src + psrc[rr], Ps + (rr * 512 + wave * 64) * 16);                                      \
+      } else {                                                                                                 \
+        const char* s_ = hc + 2 < hc_end ? patch_src + (hc + 2) * 64 : (has_next ? n_patch_src : patch_src);   \
+        ISSUE_PATCH(s_, 0);                                                                                    \
+      }                                                                                                        \
     }                                                                                                          \
     if constexpr (RES && ROWS && (D) == 6) {   /* residual of the NEXT tile (of this one again at the very end) */ \
       _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                      \
@@ -423,17 +482,45 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
     } else if (dbg & 3) WAIT_VM(0);                                                                            \
     else if ((D) == 0 && after_epi) WAIT_VM(WN_ + EPI_OPS);                                                    \
     else WAIT_VM(WN_);                                                                                         \
+    STAMP(1);                                                                                                  \
     BARRIER();                                                                                                 \
+    STAMP(2);                                                                                                  \
     if (!(dbg & 4)) MFMAS();                                                                                   \
+    STAMP(3);                                                                                                  \
+    STAMP_NEXT();                                                                                              \
     BARRIER();                                                                                                 \
   } while (0)
 
+#ifdef FLOPE_STAG_DBG
+  // dbg & 64 (diagnostic build only; MI355X_MICROARCH "DVFS give-back" item 6): shader-clock and 100 MHz real-time stamps around the
+  // FIRST tile's main loop, one record per (workgroup, wave group) into p.split_ws: {clk0, clk1, rt0, rt1}.  In-kernel clock =
+  // (clk1 - clk0) / (rt1 - rt0) * 100 MHz; cycles per double step = (clk1 - clk0) / ND (the MFMA floor is 1024).
+  unsigned long long st_c0 = 0, st_r0 = 0;
+  bool st_first = true;
+  if (dbg & 64) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
   for (;;) {
     for (int hcp = 0; hcp < nbody; ++hcp) {
       DSTEP(0); DSTEP(1); DSTEP(2); DSTEP(3); DSTEP(4); DSTEP(5); DSTEP(6); DSTEP(7); DSTEP(8);
       after_epi = false;
       hc += 2;
     }
+#ifdef FLOPE_STAG_DBG
+    if ((dbg & 64) && st_first && p.split_ws) {
+      const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();
+      if (wl == 0 && lane == 0) {
+        unsigned long long* d_ = (unsigned long long*)p.split_ws + ((size_t)blockIdx.x * 2 + group) * 4;
+        d_[0] = st_c0; d_[1] = c1_; d_[2] = st_r0; d_[3] = r1_;
+      }
+      st_first = false;
+    }
+    if ((dbg & 128) && p.split_ws && wl == 0 && lane < 4 && !st_done) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      unsigned long long* d_ = (unsigned long long*)((char*)p.split_ws + 65536) + ((size_t)blockIdx.x * 2 + group) * kStampD * 4;
+      for (int i = 0; i < st_n; ++i) d_[i * 4 + lane] = *(const unsigned long long*)(st_lds + i * 32 + lane * 8);
+    }
+    if (dbg & 128) { st_done = true; st_n = kStampD; }      // once per workgroup
+#endif
     // ---- tile finished for this wave: + bias (+ residual) (ReLU) -> 16-bit padded NHWC, straight from registers
     const bool full_tile = mend - m0 == BM;
     if (KSP > 1) {                              // split-K: raw fp32 partial sums, [ks][flat pixel][channel]
@@ -453,8 +540,21 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
       for (int pt = 0; pt < MT; ++pt) ooff[pt] = out_off(pt, ok[pt]);   // clamped: loads below are always legal
       // all residual loads first (one latency, not one per pixel tile), then compute + store
       u32x4 rv[RES ? MT : 1][2];
+      if constexpr (RES && !ROWS && BN == 128 && PT >= 4) {
+        if (res_lds) {                           // this lane's own DMA pieces: patch buffer 0 (pt 0, 1), ring slots 0 and 1 (pt 2, 3)
+          WAIT_VM(0);
+#pragma unroll
+          for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int off_ = pt < 2 ? ((pt * 2 + c) * 512 + wave * 64 + lane) * 16
+                                      : 2 * PATCH_B + (pt - 2) * DT_B + c * 8192 + wave * 1024 + lane * 16;
+              rv[pt][c] = *(const u32x4*)(smem + off_);
+            }
+        }
+      }
       if constexpr (RES && !ROWS) {
-        if (!res_pre) {
+        if (!res_pre && !res_lds) {
 #pragma unroll
           for (int pt = 0; pt < MT; ++pt) {
             const char* rp = (const char*)p.res + ooff[pt];
@@ -494,8 +594,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
             *(u32x4*)(op + c * 64) = o;
           }
         }
+        if (has_next) {                         // the next tile's accumulators start at the bias again
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = f32x4{bias[ct * 4], bias[ct * 4 + 1], bias[ct * 4 + 2], bias[ct * 4 + 3]};
+          for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = BIAS4(ct);
+        }
         if constexpr (RES && ROWS) {              // next tile's residual (prefetched at double step 6) rides in the accumulators
 #pragma unroll
           for (int ct = 0; ct < NT; ++ct)
@@ -527,6 +629,9 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvP p) {
   if (group == 0) BARRIER();                                // every wave executes the same number of barriers
   WAIT_VM(0);                                               // drain the wrapped-around tail DMAs before LDS is released
 #undef DSTEP
+#undef STAMP
+#undef STAMP_NEXT
+#undef BIAS4
 #undef ISSUE_DT
 #undef ISSUE_PATCH
 #undef WAIT_VM

@@ -47,6 +47,7 @@ thread_local std::string g_last_error;
 constexpr double kBnEps = 1e-5;
 constexpr size_t kLdsTwoBlocks = 80 * 1024;   // <= this: two workgroups per CU
 constexpr size_t kLdsMax = 160 * 1024;
+constexpr size_t kDbgRegion = 1 << 20;        // diagnostic builds: bytes of the split-K workspace per conv launch (clock stamps)
 constexpr size_t kBufSlack = 1 << 20;         // conv_stag's fixed-size patch DMA may read this far past the last pixel (zeros)
 
 struct Conv {
@@ -90,7 +91,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0;
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -484,6 +485,17 @@ extern "C" int flope_destroy(flope_handle e) {
   return FLOPE_OK;
 }
 
+// developer aid (diagnostic builds, -DFLOPE_STAG_DBG + option dbg = 64): copies `bytes` of the split-K workspace, where conv launch i
+// of the last forward left its clock stamps at byte offset i * 131072, to host memory
+extern "C" int flope_debug_read_ws(flope_handle e, void* dst_host, size_t offset, size_t bytes) {
+  if (!e || !dst_host) return fail(e, FLOPE_EINVAL, "flope_debug_read_ws: NULL argument");
+  if (!e->split_ws || offset + bytes > e->split_ws_bytes) return fail(e, FLOPE_EINVAL, "flope_debug_read_ws: out of range");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipDeviceSynchronize());
+  HIP_TRY(e, hipMemcpy(dst_host, (const char*)e->split_ws + offset, bytes, hipMemcpyDeviceToHost));
+  return FLOPE_OK;
+}
+
 extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   if (!e || !name) return fail(e, FLOPE_EINVAL, "flope_set_option: NULL argument");
   int prev;
@@ -498,6 +510,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
+  else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
+  else if (!strcmp(name, "reslds")) { prev = e->opt_reslds; e->opt_reslds = value != 0; return prev; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (!strcmp(name, "dsfuse")) { prev = e->opt_dsfuse; e->opt_dsfuse = value != 0; }
   else if (!strcmp(name, "stag")) { prev = e->opt_stag; e->opt_stag = value < 0 ? 0 : (value > 3 ? 3 : value); }
@@ -649,7 +663,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       const int sbm = c.cout == 64 ? 512 : 256;
       p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + sbm - 1) / sbm; p.ntiles = c.cout == 64 ? 1 : c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
       p.total_tiles = p.mtiles * p.ntiles;
-      p.skew = e->opt_skew;
+      p.skew = e->opt_skew; p.prio = e->opt_prio;
       if (c.ds_conv >= 0) {
         const Conv& cd = e->convs[c.ds_conv];
         p.res = nullptr; p.bias = c.bias_fused;
@@ -688,8 +702,14 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         pf.ksplit = ksp; pf.split_ws = e->split_ws;
         gridb = p.total_tiles * ksp;
       }
+      if ((e->opt_dbg & (64 | 128)) && ksp == 1 && e->split_ws)      // diagnostic build: clock stamps of this launch (flope_debug_read_ws)
+        p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
+      p.res_lds = (e->opt_reslds && p.res && c.stag == 1 && c.cout >= 128 && c.stag_patch_bytes >= 4 && ksp == 1 && gridb == p.total_tiles) ? 1 : 0;
+      size_t lds_bytes = c.stag_lds;
+      if ((e->opt_dbg & 128) && lds_bytes + 2048 <= kLdsMax) { p.dbg_lds_off = (int)lds_bytes; lds_bytes += 2048; }
+      else if (e->opt_dbg & 128) p.dbg &= ~128;
       SMARK();
-      K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, gridb, c.stag_lds, stream));
+      K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, gridb, lds_bytes, stream));
       if (ksp > 1) K_TRY(e, c.name.c_str(), flope_conv_split_finalize_launch(&pf, dt, stream));
     } else {
       ConvP p; conv_params(e, vb, c, batch, &p);

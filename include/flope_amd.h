@@ -154,6 +154,10 @@ int flope_read_stage(flope_handle h, int stage, int batch, float* dst_dev,
                      int64_t* dims_out, void* stream);
 /* runtime knobs (A/B variants inside one build); returns previous value or <0 */
 int flope_set_option(flope_handle h, const char* name, int value);
+/* developer aid of diagnostic builds (-DFLOPE_STAG_DBG, option "dbg" = 64): in-kernel clock stamps that conv launch i of
+ * the last forward left in the split-K workspace at byte offset i * 1048576 ({clk0, clk1, rt0, rt1} uint64 per workgroup and
+ * wave group; per-double-step stamps 64 KB further with "dbg" = 128) -> host memory.  A production build leaves the workspace untouched. */
+int flope_debug_read_ws(flope_handle h, void* dst_host, size_t offset, size_t bytes);
 /* algorithmic FLOPs of one forward for `batch` crops (2*MAC, convs + 2 FCs) */
 double flope_forward_flops(flope_handle h, int batch);
 /* number of kernel launches flope_forward enqueues */

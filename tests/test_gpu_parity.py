@@ -55,8 +55,8 @@ def test_f32_strict_mode_every_stage(state_dict, H, W, B):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("opts", [dict(patch=1, bm256=1, nbuf=3, fuse_stem=1, stag=2, stem_persist=2), dict(patch=0, bm256=0, nbuf=3, fuse_stem=0, stag=0),
-                                  dict(patch=1, bm256=0, nbuf=2, fuse_stem=0, stag=0), dict(patch=0, bm256=1, nbuf=2, fuse_stem=1, stag=1, dsfuse=0, gstag=0, stem_persist=0)])
+@pytest.mark.parametrize("opts", [dict(patch=1, bm256=1, nbuf=3, fuse_stem=1, stag=2, stem_persist=2, reslds=0, prio=2), dict(patch=0, bm256=0, nbuf=3, fuse_stem=0, stag=0),
+                                  dict(patch=1, bm256=0, nbuf=2, fuse_stem=0, stag=0), dict(patch=0, bm256=1, nbuf=2, fuse_stem=1, stag=1, dsfuse=0, gstag=0, stem_persist=0, skew=0, prio=1)])
 @pytest.mark.parametrize("H,W,B", [(224, 224, 5), (96, 80, 3), (65, 71, 2)])
 def test_mfma_path_every_stage_vs_emulating_oracle(state_dict, dtype, opts, H, W, B):
     torch.manual_seed(11)
