@@ -64,12 +64,22 @@ __device__ __forceinline__ unsigned pk_max16_nonneg(unsigned a, unsigned b) {
 // 16-bit store of an epilogue pair: optional ReLU, and for float16 saturation at +-65504 -- a residual stream that
 // outgrows the float16 range would otherwise become inf here, NaN one layer later and a garbage rotation with no error
 // (bfloat16 has float32's range and needs nothing).  One v_pk_min_f16 (+ v_pk_max_f16 without ReLU) per two channels.
-template <typename T> __device__ __forceinline__ unsigned pk_out16(unsigned w, bool relu) { return relu ? pk_relu16(w) : w; }
+// Branch-free (r03: written as `relu ? a : b` the compiler turned every packed pair of an epilogue into its own branch on the
+// uniform flag -- 64 branches per wave-tile, 1,250 instructions for the epilogue of one conv_w4 tile):
+//   ReLU or identity = signed-integer max with 0 or with INT16_MIN;  float16: then clamp to +-65504 (for the ReLU case the
+//   lower clamp is a no-op on a non-negative value).  Same results, bit for bit, as the two-path form.
+template <typename T> __device__ __forceinline__ unsigned pk_out16(unsigned w, bool relu) {
+  const short zl = relu ? (short)0 : (short)-32768;
+  const i16x2_t z = {zl, zl};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
+}
 template <> __device__ __forceinline__ unsigned pk_out16<f16_t>(unsigned w, bool relu) {
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   const h2_t hi = {(_Float16)65504.f, (_Float16)65504.f}, lo = {(_Float16)-65504.f, (_Float16)-65504.f};
-  if (relu) return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(h2_t, pk_relu16(w)), hi));
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(h2_t, w), hi), lo));
+  const short zl = relu ? (short)0 : (short)-32768;
+  const i16x2_t z = {zl, zl};
+  const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(h2_t, x), hi), lo));
 }
 
 // Bijective XCD-aware block remap (blocks b and b+8 share an XCD under the
@@ -129,6 +139,7 @@ struct ConvP {
   int res_lds;
   int prio;            // conv_stag: 1 = s_setprio 1 for waves 4..7, 2 = for waves 0..3, 0 = none
   int dbg_lds_off;     // diagnostic builds, dbg & 128: LDS byte offset of the stamp area (behind the kernel's own image)
+  unsigned mg_pitch, sh_pitch;   // conv_w4: n / (Wip + 2) as multiply-shift (the skewed patch image's row pitch in pixels)
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

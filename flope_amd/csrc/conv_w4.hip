@@ -1,0 +1,470 @@
+// conv_w4: 3x3 / stride-1 implicit-GEMM convolution on flat 256 px x 128 ch tiles (layer2..4 of the ResNet-18 trunk,
+// reference sunflower/models/posenet.py:25) -- third-generation structure (r03): FOUR waves, one per SIMD.
+//
+// Why (r03 in-kernel stamps of conv_stag, profiles/r03_phase_stamps_conv_stag.txt + r03_inkernel_clock_*.txt): the chip holds
+// 2.1-2.4 GHz inside these loops -- not the ~1.55 GHz r02 had inferred from an MFMA-only ablation -- so the matrix pipe was not
+// clock-bound, it was waiting.  conv_stag's two staggered 4-wave groups alternate a load half (DMA issue + 16 ds_read_b128 +
+// waits, ~600 cycles) and an MFMA half (32 MFMAs, ~640 cycles with the partner's issue traffic) separated by TWO workgroup
+// barriers per double step (~170 cycles each from last arrival to release): ~1600 cycles per double step against a 1024-cycle
+// MFMA floor.  Here:
+//   * a wave owns 128 px x 64 ch (8 x 4 MFMA tiles, 128 accumulator registers -- the 512-register budget of one wave per
+//     SIMD): 12 fragment reads per 32 MFMAs instead of 16 (LDS bytes per MFMA -25 %);
+//   * software pipelining INSIDE the wave: while the 32 MFMAs of sub-step u issue, the wave's own 12 ds_read_b128 of
+//     sub-step u + 1 and its LDS-DMA pieces go out in the gaps (an MFMA holds the vector issue for 8 of its 16 cycles), into
+//     the second fragment register set -- no partner wave, no load half;
+//   * ONE barrier per double step (64 MFMAs per wave), in the middle of it: the wave waits for its DMA pieces of the next
+//     double tile (counted vmcnt), then the barrier publishes them; the reads of the following sub-step come after it.
+// Same LDS images (conflict-free patch image of conv_stag r03, weight ring of double tiles), same packed weights, same
+// register epilogue (lane = one pixel x 16 channels in two runs of 8), same folded 1x1 stride-2 shortcut, residual by
+// LDS-DMA in the slots the look-ahead of the last body leaves unused.  One tile per workgroup; split-K and persistent grids
+// stay on conv_stag.
+#include "common.h"
+
+#define GLDS16(gptr, lptr)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),          \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 12 ? 2 * (c - 4) + 1 : 2 * (c - 8)); }
+
+// PT: 8 KB DMA rounds per patch buffer (4, 5 or 6).  NBD: double tiles in the weight ring (3 or 4; the DMA runs NBD - 1
+// double steps ahead of its consumer).  RES: residual input.  DSF: folded 1x1 stride-2 shortcut (no residual).
+template <typename T, int PT, bool RES, bool DSF, int NBD>
+__global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int BM = 256, TILE_B = 128 * 64, DT_B = 2 * TILE_B, MT = 8, NT = 4;
+  constexpr int PATCH_B = PT * 8192;
+  constexpr int PD = NBD - 1;                              // double tiles in flight ahead of the one being consumed
+  constexpr int TGW = DT_B / 4096;                         // LDS-DMA ops per wave per double tile (4)
+  constexpr int PW = 2 * PT;                               // ... per patch burst
+  static_assert(!(RES && DSF) && PT >= 4 && NBD >= 3 && NBD <= 6, "conv_w4 variants");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ps = smem;                                   // 2 patch buffers
+  char* const Bs = smem + 2 * PATCH_B;                     // NBD double tiles of weights
+
+#ifdef FLOPE_STAG_DBG
+  // diagnostic build, dbg & 64: shader-clock stamps {entry, loop start, loop end, exit} + 100 MHz real time {loop start, loop end}
+  // of wave 0, one record of 6 x uint64 per workgroup at p.split_ws (tools/clock_probe.py)
+  const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st_p[4] = {0, 0, 0, 0};
+#define W4_PSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); st_p[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define W4_PSTAMP(i_) do {} while (0)
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpx = wave & 1, wch = wave >> 1;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int pcol = tile_px_w4(r16);
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = lb % p.ntiles;
+  const int HoWo = p.Ho * p.Wo;
+  const int nhc = p.Cin / 32;
+  const int NS = nhc * 9;
+  const int nbody = nhc / 2, ND = nbody * 9;               // double steps of this tile
+  const size_t pixB = (size_t)p.Cin * 2;
+  const size_t rowB = (size_t)p.Wip * pixB;
+  const int pitch = p.Wip + 2;                             // conflict-free patch image (conv_stag.hip, r03)
+
+  const int m0 = (lb / p.ntiles) * BM, mend = min(m0 + BM, p.M);
+  const int b0 = fastdiv(m0, p.mg_hw, p.sh_hw), ho0 = fastdiv(m0 - b0 * HoWo, p.mg_w, p.sh_w);
+  const int R0 = b0 * p.Hip + ho0;
+  const char* const patch_src = (const char*)p.in + (size_t)R0 * rowB;
+
+  const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + wave * 1024 + lane * 16;
+  const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
+  const int wbase = 2 * PATCH_B + (wch * 64 + r16) * 64 + ((g ^ wsw) << 4);
+  const int cb = ntile * 128 + wch * 64 + g * 8;
+  const float* const bias_p = p.bias + cb;
+
+#define W4_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define W4_BARRIER()                                                                                           \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    asm volatile("" ::: "memory");                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    asm volatile("" ::: "memory");                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#define W4_ISSUE_PATCH(src_, buf_)                                                                             \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < PW; ++j)                                                             \
+      GLDS16((src_) + psrc[j], Ps + (buf_) * PATCH_B + (j * 256 + wave * 64) * 16);                            \
+  } while (0)
+#define W4_ISSUE_DT(dt_, slotb_)   /* slotb_: byte offset of the ring slot */                                   \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int o = 0; o < TGW; ++o)                                                            \
+      GLDS16(b_base + (size_t)(dt_) * DT_B + o * 4096, Bs + (slotb_) + o * 4096 + wave * 1024);                \
+  } while (0)
+
+  // the bias first: an ordinary global load -- hipcc waits vmcnt(0) at its first use, which would drain every LDS-DMA issued before
+  // that point, so the use (accumulator init) is pinned behind the address tables, where this wave waits for its DMAs anyway
+  f32x4 b4[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) b4[ct] = *(const f32x4*)(bias_p + (ct >> 1) * 32 + (ct & 1) * 4);
+
+  // ---- prologue, ordered by latency (r03 stamps: the address tables below are ~1,500 vector instructions = 3 us of a wave that
+  // has its SIMD to itself; issued behind them, the first DMAs added their own 1.5 us of flight time to every tile): the first PD
+  // double tiles of weights need nothing but the tile's channel block -> out first; then the shortcut's first gather (DSF), the
+  // first patch; the tables are computed while all of that is in flight.
+  W4_PSTAMP(0);
+#pragma unroll
+  for (int d = 0; d < PD; ++d) W4_ISSUE_DT(d, d * DT_B);
+
+  // DSF: folded 1x1 stride-2 shortcut (conv_stag.hip): per 64 channels of the block input x, the tile's 256 centre pixels
+  // x(2 ho, 2 wo) as two 32-channel pixel tiles in patch buffer 1, the matching double tile of shortcut weights in the LAST ring
+  // slot, one double step of MFMAs into the same accumulators (which start at bias2 + bias_ds)
+  const char* dsrc[DSF ? 4 : 1];
+  const char* dw_base = nullptr;
+#define W4_ISSUE_DS(j_)                                                                                        \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                              \
+      _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                         \
+        GLDS16(dsrc[rr] + (2 * (j_) + t) * 64, Ps + PATCH_B + t * 16384 + (rr * 256 + wave * 64) * 16);        \
+    _Pragma("unroll") for (int o = 0; o < TGW; ++o)                                                            \
+      GLDS16(dw_base + (size_t)(j_) * DT_B + o * 4096, Bs + (NBD - 1) * DT_B + o * 4096 + wave * 1024);        \
+  } while (0)
+  if constexpr (DSF) {
+    const size_t dpix = (size_t)p.ds_Cin * 2;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int q = rr * 256 + wave * 64 + lane, sl = q >> 2;
+      const int m = min(m0 + sl, mend - 1);
+      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+      dsrc[rr] = (const char*)p.ds_in + (((size_t)b_ * p.ds_Hip + 2 * ho_ + 1) * p.ds_Wip + 2 * wo_ + 1) * dpix +
+                 (((q & 3) ^ ((sl >> 2) & 3)) << 4);
+    }
+    dw_base = (const char*)p.ds_w + (size_t)ntile * (p.ds_Cin / 32) * TILE_B + wave * 1024 + lane * 16;
+    W4_ISSUE_DS(0);
+  }
+
+  // per-lane DMA source offsets of a patch burst: op j = 2 rr + h moves pieces rr * 512 + h * 256 + wave * 64 + lane
+  unsigned psrc[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int q = j * 256 + wave * 64 + lane;
+    const int pi = q >> 2;
+    const int pr_ = fastdiv(pi, p.mg_pitch, p.sh_pitch), pc_ = pi - __mul24(pr_, pitch);
+    const int js = (q & 3) ^ (((__mul24(pr_, p.Wo) + pc_) >> 2) & 3);
+    psrc[j] = (unsigned)(__mul24(__mul24(pr_, p.Wip) + min(pc_, p.Wip - 1), (int)pixB) + js * 16);
+  }
+  W4_ISSUE_PATCH(patch_src, 0);
+  W4_PSTAMP(1);
+
+  // fragment address table: xoff[t][pt] = LDS byte offset of this lane's pixel fragment of pixel tile pt for tap t
+  //   = (pi << 6) + ((g ^ ((sv >> 2) & 3)) << 4),  pi = pi0 + dy * pitch + dx,  sv = v0 + dy * W + dx
+  // in three vector instructions per entry (r03: the table was ~7 per entry, half of a 5 k-cycle prologue):
+  //   ((g ^ ((sv >> 2) & 3)) << 4) = ((sv << 2) ^ (g << 4)) & 0x30;  the tap terms are wave-uniform (scalar registers)
+  int xoff[9][MT];
+  unsigned ooff[MT];                                       // byte offset of this lane's 16 channels of pixel tile pt in the padded output
+  bool ok[MT];
+  int tap_p[9], tap_v[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    tap_p[t] = ((t / 3) * pitch + (t % 3)) << 6;
+    tap_v[t] = ((t / 3) * p.Wo + (t % 3)) << 2;
+  }
+  const int g4 = g << 4;
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    const int mm = m0 + wpx * 128 + pt * 16 + pcol;
+    ok[pt] = mm < mend;
+    const int m_ = min(mm, mend - 1);
+    // (24-bit multiplies: full-rate instructions, every factor here is far below 2^24)
+    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo);
+    const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);
+    const int i_ = __mul24(b_, p.Hip) + ho_ - R0;
+    const int pb = (__mul24(i_, pitch) + wo_) << 6, vb = (__mul24(i_, p.Wo) + wo_) << 2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) xoff[t][pt] = pb + tap_p[t] + (((vb + tap_v[t]) ^ g4) & 0x30);
+    ooff[pt] = (unsigned)((__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) + cb) * 2);
+  }
+
+  // pin the tables in FRONT of the DMA wait (left alone, the compiler sinks these ~800 pure vector instructions behind the wait
+  // and the barrier, next to their first use -- the DMA flight time and the table time then add up instead of overlapping)
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    asm volatile("" ::"v"(xoff[t][0]), "v"(xoff[t][1]), "v"(xoff[t][2]), "v"(xoff[t][3]), "v"(xoff[t][4]), "v"(xoff[t][5]), "v"(xoff[t][6]), "v"(xoff[t][7]));
+  asm volatile("" ::"v"(ooff[0]), "v"(ooff[1]), "v"(ooff[2]), "v"(ooff[3]), "v"(ooff[4]), "v"(ooff[5]), "v"(ooff[6]), "v"(ooff[7]));
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) acc[pt][ct] = b4[ct];
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt)                          // ... and the accumulator init too (128 register moves)
+    asm volatile("" : "+a"(acc[pt][0]), "+a"(acc[pt][1]), "+a"(acc[pt][2]), "+a"(acc[pt][3]));
+  frag wf[2][NT], xf[2][MT];                               // two fragment sets: sub-step u uses set u & 1
+
+  W4_PSTAMP(2);
+  W4_WAIT_VM(0);                                            // patch 0, the first double tiles (and the shortcut's first gather) landed
+  W4_BARRIER();
+  W4_PSTAMP(3);
+
+  if constexpr (DSF) {
+    int xds[MT];
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) {
+      const int sl = wpx * 128 + pt * 16 + pcol;
+      xds[pt] = PATCH_B + (sl << 6) + ((g ^ ((sl >> 2) & 3)) << 4);
+    }
+    for (int j = 0; j < p.ds_Cin / 64; ++j) {
+      if (j > 0) {
+        W4_ISSUE_DS(j);
+        W4_WAIT_VM(0);
+        W4_BARRIER();
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) wf[h][ct] = *(const frag*)(smem + wbase + (NBD - 1) * DT_B + h * TILE_B + ct * 1024);
+#pragma unroll
+        for (int pt = 0; pt < MT; ++pt) xf[h][pt] = *(const frag*)(smem + xds[pt] + h * 16384);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[h][ct], xf[h][pt], acc[pt][ct]);
+      W4_BARRIER();                                        // buffer 1 / the last ring slot are free again
+    }
+  }
+
+  // fragments of sub-step 0: double tile 0 (slot 0), half 0; patch buffer 0, tap 0
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) wf[0][ct] = *(const frag*)(smem + wbase + ct * 1024);
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) xf[0][pt] = *(const frag*)(smem + xoff[0][pt]);
+
+  // One sub-step: the 32 MFMAs of fragment set C_ with the 12 fragment reads of the NEXT sub-step (set N_: weights at LDS
+  // byte offset wo_, pixel fragments of patch buffer nb_ / tap nt_) issued in their gaps, 4 weight fragments first, and -- in
+  // the second sub-step of a double step -- this wave's LDS-DMA pieces (DMA_(i): piece i of the double step's NV_ pieces, KV_ per
+  // group of 4 MFMAs; an LDS-DMA issue costs ~60 cycles of the wave's issue time among MFMAs: spread out, never in front of
+  // them).  Program order IS the wanted order (the compiler keeps LDS-DMA and ds_read in program order: both touch LDS);
+  // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.
+#define W4_NODMA(i_) do {} while (0)
+#define W4_GRP(P_, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                      \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
+      acc[P_][ct] = Elem<T>::mfma(wf[C_][ct], xf[C_][P_], acc[P_][ct]);                                        \
+    if constexpr ((P_) < 2) {                                                                                  \
+      wf[N_][2 * (P_)] = *(const frag*)(smem + (wo_) + (2 * (P_)) * 1024);                                     \
+      wf[N_][2 * (P_) + 1] = *(const frag*)(smem + (wo_) + (2 * (P_) + 1) * 1024);                             \
+    } else if constexpr ((P_) < 6) {                                                                           \
+      xf[N_][2 * ((P_) - 2)] = *(const frag*)(smem + xoff[nt_][2 * ((P_) - 2)] + (nb_) * PATCH_B);             \
+      xf[N_][2 * ((P_) - 2) + 1] = *(const frag*)(smem + xoff[nt_][2 * ((P_) - 2) + 1] + (nb_) * PATCH_B);     \
+    }                                                                                                          \
+    if constexpr ((KV_) > 0 && (P_) * (KV_) + 0 < (NV_)) DMA_(((P_) * (KV_) + 0));                             \
+    if constexpr ((KV_) > 1 && (P_) * (KV_) + 1 < (NV_)) DMA_(((P_) * (KV_) + 1));                             \
+    if constexpr ((KV_) > 2 && (P_) * (KV_) + 2 < (NV_)) DMA_(((P_) * (KV_) + 2));                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                         \
+    if constexpr ((P_) < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                 \
+    if constexpr ((KV_) > 0 && (P_) * (KV_) < (NV_))                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x020, (((P_) + 1) * (KV_) <= (NV_) ? (KV_) : (NV_) - (P_) * (KV_)), 0); \
+  } while (0)
+#define W4_SUB(C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                          \
+  do {                                                                                                         \
+    W4_GRP(0, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(1, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
+    W4_GRP(2, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(3, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
+    W4_GRP(4, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(5, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
+    W4_GRP(6, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(7, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
+  } while (0)
+
+  int dn = PD;                                             // next double tile to issue
+  int slot_b = 0;                                          // byte offset of the ring slot of the double tile being consumed
+  int hc = 0;                                              // first half-chunk of the current body
+  int res_slot[2] = {0, 0};                                // ring slots (byte offsets) that received residual pieces of pixel tiles 4, 5 / 6, 7
+
+  // double step D of a body: sub-steps u0 = 2 D, u1 = 2 D + 1 (tap u % 9 of half-chunk u / 9); the sub-step after u1 is 2 D + 2
+  // (D = 8: the next body's first).  DMA pieces of the double step: 0 .. TGW - 1 = double tile D + PD into the slot PD ahead;
+  // then, at D = 0 and D = 5, the PW pieces of a patch burst.  RES, last body: the burst of D = 5 (the next tile's patch: unused)
+  // and the double tiles of D = 7, 8 (they wrap to the start of the panel: unused) carry the tile's residual instead --
+  // 8 + 4 + 4 pieces per lane, the 16 bytes each lane adds itself in the epilogue.
+#define W4_DMA_PIECE(i_)                                                                                       \
+  do {                                                                                                         \
+    if constexpr ((i_) < TGW) {                                                                                \
+      if (RES && lastb_ && (D_ == 7 || D_ == 8)) {                                                             \
+        unsigned ro_ = ooff[4 + 2 * RS_ + (((i_) >> 1) & 1)]; asm volatile("" : "+v"(ro_));                    \
+        GLDS16((const char*)p.res + ro_ + ((i_) & 1) * 64, Bs + iss_b_ + (i_) * 4096 + wave * 1024);           \
+      } else {                                                                                                 \
+        GLDS16(b_base + (size_t)di_ * DT_B + (i_) * 4096, Bs + iss_b_ + (i_) * 4096 + wave * 1024);            \
+      }                                                                                                        \
+    } else {                                                                                                   \
+      constexpr int j_ = (i_) - TGW < 0 ? 0 : ((i_) - TGW >= PW ? PW - 1 : (i_) - TGW);                        \
+      if (D_ == 0) {                                                                                           \
+        GLDS16(patch_src + (hc + 1) * 64 + psrc[j_], Ps + PATCH_B + (j_ * 256 + wave * 64) * 16);              \
+      } else if (RES && lastb_ && j_ < 8) {                                                                    \
+        unsigned ro_ = ooff[j_ >> 1]; asm volatile("" : "+v"(ro_));                                            \
+        GLDS16((const char*)p.res + ro_ + (j_ & 1) * 64, Ps + (j_ * 256 + wave * 64) * 16);                    \
+      } else {                                                                                                 \
+        GLDS16(patch_src + (hc + 2 < nhc ? (hc + 2) * 64 : 0) + psrc[j_], Ps + (j_ * 256 + wave * 64) * 16);   \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+#define W4_DSTEP(D)                                                                                            \
+  do {                                                                                                         \
+    constexpr int D_ = (D), U1_ = 2 * (D) + 1, U2_ = (2 * (D) + 2) % 18, RS_ = (D) == 8 ? 1 : 0;               \
+    /* vmcnt at the barrier: everything but the ops younger than double tile D + 1 -- the PD - 2 later double tiles and a patch \
+       burst issued in the second sub-step of double step Dp in {0, 5} while D + 1 - PD <= Dp <= D - 1 */      \
+    /* (PD >= 5: a burst of D = 5 would still be younger at the NEXT body's D = 0; not counted there -- the first body has none --   \
+       which only makes that one wait stricter than it needs to be) */                                          \
+    constexpr int WN_ = TGW * (PD - 2) + ((((D) >= 1 && (D) <= PD - 1) || ((D) >= 6 && (D) <= PD + 4)) ? PW : 0); \
+    constexpr int NV_ = TGW + (((D) == 0 || (D) == 5) ? PW : 0), KV_ = (NV_ + 7) / 8;                          \
+    const int next_b_ = slot_b + DT_B >= NBD * DT_B ? 0 : slot_b + DT_B;                                       \
+    int wof_ = wbase + slot_b, wofn_ = wbase + next_b_;                                                        \
+    asm volatile("" : "+v"(wof_), "+v"(wofn_));                                                                \
+    W4_SUB(0, 1, wof_ + TILE_B, U1_ / 9, U1_ % 9, 0, 0, W4_NODMA);                                             \
+    W4_WAIT_VM(WN_);                                                                                           \
+    W4_BARRIER();                                                                                              \
+    int iss_b_ = slot_b + PD * DT_B; if (iss_b_ >= NBD * DT_B) iss_b_ -= NBD * DT_B;                           \
+    const bool lastb_ = hc + 2 >= nhc;                                                                         \
+    const int di_ = dn < ND ? dn : dn - ND;                                                                    \
+    if (RES && lastb_ && ((D) == 7 || (D) == 8)) res_slot[RS_] = iss_b_;                                       \
+    ++dn;                                                                                                      \
+    W4_SUB(1, 0, wofn_, U2_ / 9, U2_ % 9, NV_, KV_, W4_DMA_PIECE);                                             \
+    slot_b = next_b_;                                                                                          \
+  } while (0)
+
+#ifdef FLOPE_STAG_DBG
+  const unsigned long long st_l0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int hcp = 0; hcp < nbody; ++hcp) {
+    W4_DSTEP(0); W4_DSTEP(1); W4_DSTEP(2); W4_DSTEP(3); W4_DSTEP(4); W4_DSTEP(5); W4_DSTEP(6); W4_DSTEP(7); W4_DSTEP(8);
+    hc += 2;
+  }
+
+#ifdef FLOPE_STAG_DBG
+  const unsigned long long st_l1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- epilogue: (+ residual) (ReLU) -> 16-bit padded NHWC straight from the accumulators
+  W4_WAIT_VM(0);                                           // look-ahead DMAs (and the residual rounds) have landed
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    float v[NT * 4];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
+    if constexpr (RES) {
+      {                                                    // this lane's own DMA pieces (no other wave reads them)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int off_ = pt < 4 ? ((pt * 2 + c) * 256 + wave * 64 + lane) * 16
+                                  : 2 * PATCH_B + res_slot[(pt - 4) >> 1] + (((pt - 4) & 1) * 2 + c) * 4096 + wave * 1024 + lane * 16;
+          const u32x4 rv = *(const u32x4*)(smem + off_);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[c * 8 + q * 2] += unpack_lo<T>(rv[q]);
+            v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[q]);
+          }
+        }
+      }
+    }
+    if (ok[pt]) {
+      char* op = (char*)p.out + ooff[pt];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pk_out16<T>(pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]), p.relu);
+        *(u32x4*)(op + c * 64) = o;
+      }
+    }
+  }
+#ifdef FLOPE_STAG_DBG
+  if ((p.dbg & 64) && p.split_ws && wave == 0 && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* d_ = (unsigned long long*)p.split_ws + (size_t)blockIdx.x * 8;
+    d_[0] = st_e0; d_[1] = st_l0; d_[2] = st_l1; d_[3] = __builtin_amdgcn_s_memtime(); d_[4] = st_r0; d_[5] = st_r1;
+    unsigned long long* q_ = (unsigned long long*)((char*)p.split_ws + 65536) + (size_t)blockIdx.x * 4;
+    q_[0] = st_p[0]; q_[1] = st_p[1]; q_[2] = st_p[2]; q_[3] = st_p[3];
+  }
+#endif
+#undef W4_PSTAMP
+#undef W4_DSTEP
+#undef W4_ISSUE_DS
+#undef W4_DMA_PIECE
+#undef W4_NODMA
+#undef W4_SUB
+#undef W4_GRP
+#undef W4_ISSUE_DT
+#undef W4_ISSUE_PATCH
+#undef W4_BARRIER
+#undef W4_WAIT_VM
+}
+
+template <typename T, bool RES, bool DSF, int NBD>
+static hipError_t w4_attr_pt() {
+  hipError_t e = hipSuccess;
+#define A(PT_) if (e == hipSuccess && 2 * PT_ * 8192 + NBD * 16384 <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A(4) A(5) A(6)
+#undef A
+  return e;
+}
+template <typename T, int NBD>
+static hipError_t w4_attr_n() {
+  hipError_t e = w4_attr_pt<T, false, false, NBD>();
+  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD>();
+  return e;
+}
+template <typename T>
+static hipError_t w4_attr() {
+  hipError_t e = w4_attr_n<T, 3>();
+  if (e == hipSuccess) e = w4_attr_n<T, 4>();
+  if (e == hipSuccess) e = w4_attr_n<T, 5>();
+  if (e == hipSuccess) e = w4_attr_n<T, 6>();
+  return e;
+}
+
+extern "C" int flope_conv_w4_init() {
+  hipError_t e = w4_attr<bf16_t>();
+  if (e == hipSuccess) e = w4_attr<f16_t>();
+  return (int)e;
+}
+
+template <typename T, bool RES, bool DSF, int NBD>
+static void w4_go(const ConvP& p, int pt, size_t lds, hipStream_t st) {
+  const dim3 grid(p.total_tiles), block(256);
+  switch (pt) {
+    case 4: hipLaunchKernelGGL((conv_w4_kernel<T, 4, RES, DSF, NBD>), grid, block, lds, st, p); break;
+    case 5: hipLaunchKernelGGL((conv_w4_kernel<T, 5, RES, DSF, NBD>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_w4_kernel<T, 6, RES, DSF, NBD>), grid, block, lds, st, p); break;
+  }
+}
+template <typename T, int NBD>
+static void w4_go_n(const ConvP& p, int pt, size_t lds, hipStream_t st) {
+  if (p.ds_in) w4_go<T, false, true, NBD>(p, pt, lds, st);
+  else if (p.res) w4_go<T, true, false, NBD>(p, pt, lds, st);
+  else w4_go<T, false, false, NBD>(p, pt, lds, st);
+}
+
+// lds bytes needed: 2 * PT * 8192 + nbd * 16384
+extern "C" size_t flope_conv_w4_lds(int pt, int nbd) { return (size_t)2 * pt * 8192 + (size_t)nbd * 16384; }
+
+// 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch), one tile per
+// workgroup: p->patch_rows_max = PT (4, 5 or 6), p->total_tiles = ceil(M / 256) * Cout / 128, p->w the conv_stag weight image.
+// nbd = 3..6 double tiles in the weight ring (the DMA runs nbd - 1 double steps ahead).
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, void* stream) {
+  const int pt = p->patch_rows_max;
+  if (p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 6 ||
+      (pt != 4 && pt != 5 && pt != 6) || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)))
+    return (int)hipErrorInvalidValue;
+  const size_t lds = flope_conv_w4_lds(pt, nbd);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T)                                                                                                  \
+  do {                                                                                                         \
+    switch (nbd) {                                                                                             \
+      case 3: w4_go_n<T, 3>(*p, pt, lds, st); break;                                                           \
+      case 4: w4_go_n<T, 4>(*p, pt, lds, st); break;                                                           \
+      case 5: w4_go_n<T, 5>(*p, pt, lds, st); break;                                                           \
+      default: w4_go_n<T, 6>(*p, pt, lds, st); break;                                                          \
+    }                                                                                                          \
+  } while (0)
+  if (dtype == 0) GO(bf16_t); else GO(f16_t);
+#undef GO
+  return (int)hipGetLastError();
+}

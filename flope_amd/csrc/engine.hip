@@ -31,6 +31,9 @@ extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C,
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
 extern "C" int flope_conv_stag_init();
 extern "C" int flope_conv_gstag_init();
+extern "C" int flope_conv_w4_init();
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, void* stream);
+extern "C" size_t flope_conv_w4_lds(int pt, int nbd);
 extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
@@ -91,7 +94,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0;
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_w4 = 6;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -385,6 +388,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     if (s == 0) s = flope_stem_pool_init();
     if (s == 0) s = flope_conv_stag_init();
     if (s == 0) s = flope_conv_gstag_init();
+    if (s == 0) s = flope_conv_w4_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
   const size_t B = (size_t)max_batch;
@@ -510,6 +514,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
+  else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = (value >= 3 && value <= 6) ? value : 0; return prev; }
   else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "reslds")) { prev = e->opt_reslds; e->opt_reslds = value != 0; return prev; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -592,6 +597,12 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
 // batch-major, so a slice is just an offset view of the same buffers.
 // head: fc_rot + Procrustes of this slice on the slice's own stream (so a slice's head overlaps the other slice's
 // trunk instead of running after the join); r9_dev / R_dev are the caller's full-batch buffers, head = false skips it.
+// static part of the choice between conv_w4 (4 waves) and conv_stag for a flat 256 x 128 conv (split-K at small batches and
+// persistent grids still take conv_stag at launch time)
+static bool w4_eligible(const flope_engine* e, const Conv& c) {
+  return e->opt_w4 && !e->opt_persist && c.stag == 1 && c.cout >= 128 && e->opt_skew && c.stag_patch_bytes >= 4 && c.stag_patch_bytes <= 6;
+}
+
 struct PoseOut { const float* xyz = nullptr; int nullify = 0; float* Rt = nullptr; };   // optional [B,16] pose assembly
 
 static int run_slice(flope_engine* e, const void* x_dev, int in_format, int start, int batch, void* stream, bool marks,
@@ -702,9 +713,20 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         pf.ksplit = ksp; pf.split_ws = e->split_ws;
         gridb = p.total_tiles * ksp;
       }
+      p.res_lds = (e->opt_reslds && p.res && c.stag == 1 && c.cout >= 128 && c.stag_patch_bytes >= 4 && ksp == 1 && gridb == p.total_tiles) ? 1 : 0;
       if ((e->opt_dbg & (64 | 128)) && ksp == 1 && e->split_ws)      // diagnostic build: clock stamps of this launch (flope_debug_read_ws)
         p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
-      p.res_lds = (e->opt_reslds && p.res && c.stag == 1 && c.cout >= 128 && c.stag_patch_bytes >= 4 && ksp == 1 && gridb == p.total_tiles) ? 1 : 0;
+      // r03: flat 256 x 128 tiles, one tile per workgroup, no split-K -> the 4-wave kernel (conv_w4.hip)
+      if (w4_eligible(e, c) && ksp == 1 && gridb == p.total_tiles && !(e->opt_dbg & 128)) {
+        int nbd = e->opt_w4;                               // weight-ring depth asked for; the deepest that fits the CU's LDS
+        while (nbd > 3 && flope_conv_w4_lds(c.stag_patch_bytes, nbd) > kLdsMax) --nbd;
+        if (flope_conv_w4_lds(c.stag_patch_bytes, nbd) <= kLdsMax) {
+          fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
+          SMARK();
+          K_TRY(e, c.name.c_str(), flope_conv_w4_launch(&p, dt, nbd, stream));
+          continue;
+        }
+      }
       size_t lds_bytes = c.stag_lds;
       if ((e->opt_dbg & 128) && lds_bytes + 2048 <= kLdsMax) { p.dbg_lds_off = (int)lds_bytes; lds_bytes += 2048; }
       else if (e->opt_dbg & 128) p.dbg &= ~128;
@@ -887,6 +909,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
     else if (c.stag == 3) snprintf(k, sizeof k, "conv_gstag_kernel<256x128,s2>");
+    else if (w4_eligible(e, c)) snprintf(k, sizeof k, "conv_w4_kernel<256x128>");
     else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
@@ -914,8 +937,9 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
   for (const Conv& c : e->convs) {
     if (c.stag == 3) { snprintf(line, sizeof line, "%s: 3x3 s2 %d->%d out %dx%d conv_gstag 256x128 (gathered tiles) lds=147456\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
-    if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
+    if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d %s 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, w4_eligible(e, c) ? "conv_w4" : "conv_stag", c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
     if (c.stag == 2 && c.nseg > 1) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x %d column segments of 64 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.nseg, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
+    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, std::min(e->opt_w4, (int)((kLdsMax - 2 * c.stag_patch_bytes * 8192) / 16384)))); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);

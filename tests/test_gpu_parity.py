@@ -99,8 +99,11 @@ def test_layer1_row_band_kernel_every_stage(state_dict, H, W, B, streams):
 
 
 @pytest.mark.parametrize("H,W,B,dtype", [(224, 224, 19, "f16"), (224, 224, 3, "bf16"), (200, 136, 7, "f16"), (512, 512, 2, "f16"), (96, 80, 5, "f16")])
-def test_conflict_free_patch_image_does_not_change_a_bit(state_dict, H, W, B, dtype):
-    """conv_stag flat tiles (layers 2-4), r03: the LDS image of the input patch has row pitch W + 4 and takes its slot swizzle
+def test_conflict_free_patch_image_and_4_wave_kernel_do_not_change_a_bit(state_dict, H, W, B, dtype):
+    """conv_w4 (r03 default for the flat 256 x 128 tiles of layers 2-4: four waves, one per SIMD, fragment reads and LDS-DMA issued
+    in the gaps of the wave's own MFMAs, one barrier per double step) walks K in the same order per accumulator as conv_stag (two
+    staggered 4-wave groups), folds the shortcut first and adds the residual last, as conv_stag does: bit-identical.
+    conv_stag flat tiles (layers 2-4), r03: the LDS image of the input patch has row pitch W + 4 and takes its slot swizzle
     from i * W + c (option skew = 1, default) so that fragment reads stay conflict-free across the row wraps of 28 / 14 / 7-wide
     maps.  Only WHERE a pixel sits in LDS changes: every MFMA sees the same operands in the same order as with the r02 image
     (skew = 0), so every stage and the rotations are bit-identical -- on even and odd map widths (25 / 13 / 7 at 200 x 136: odd
@@ -108,15 +111,16 @@ def test_conflict_free_patch_image_does_not_change_a_bit(state_dict, H, W, B, dt
     torch.manual_seed(21)
     x = torch.rand(B, 3, H, W)
     outs = []
-    for skew in (1, 0):
-        e = _engine(state_dict, H, W, B, dtype, skew=skew)
+    for skew, w4 in ((1, 6), (1, 5), (1, 4), (1, 3), (1, 0), (0, 0)):     # w4: the 4-wave kernel (weight ring of <= 3..6 double tiles) or conv_stag
+        e = _engine(state_dict, H, W, B, dtype, skew=skew, w4=w4)
         r9, R = _run(e, x)
         outs.append([r9, R] + [e.read_stage(s, B).cpu() for s in STAGES if s != "stem"])
         plan = e.describe_plan()
         e.close()
-    assert "conv_stag 256x128" in plan
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    assert "conv_w4 256x128" in plan or "conv_stag 256x128" in plan
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
     emu = O.forward_stages_emulated(state_dict, x, TDT[dtype])
     assert _rel(outs[0][0], emu["r9"]) <= (2e-3 if dtype == "f16" else 1e-2)
 

@@ -1,0 +1,53 @@
+"""conv_w4 timeline per workgroup (diagnostic build): cycles before / inside / after the main loop and the in-kernel clock.
+    make dbg && FLOPE_AMD_LIB=build/dbg/libflope_amd_dbg.so python tools/clock_probe_w4.py [streams] [opts]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flope_amd.engine import PoseEngine  # noqa: E402
+from flope_amd.weights import synthetic_state_dict  # noqa: E402
+
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+B, S = int(os.environ.get("B", 256)), int(os.environ.get("S", 224))
+sd = synthetic_state_dict(0)
+x = torch.rand(B, S, S, 3).to(torch.float16).cuda()
+R = torch.empty(B, 9, device="cuda")
+e = PoseEngine(S, S, B, "f16")
+e.set_option("streams", streams)
+for kv in (sys.argv[2].split(",") if len(sys.argv) > 2 else []):
+    k, v = kv.split("=")
+    e.set_option(k, int(v))
+e.load_state_dict(sd)
+e.set_option("dbg", 64)
+t0 = time.time()
+while time.time() - t0 < 2.5:
+    for _ in range(50):
+        e.forward_into(x, 2, None, R)
+    torch.cuda.synchronize()
+buf = np.zeros(1024 * 8, dtype=np.uint64)
+print(f"B={B} S={S} streams={streams}  conv_w4 workgroups: cycles entry->loop | loop | loop->exit, clock")
+for i in (6, 7, 8, 11, 12, 13, 16, 17, 18):
+    rc = e.lib.flope_debug_read_ws(e.handle, buf.ctypes.data_as(C.c_void_p), C.c_size_t(i * 1048576), C.c_size_t(buf.nbytes))
+    assert rc == 0
+    r = buf.reshape(-1, 8).astype(np.int64)
+    ok = (r[:, 1] > r[:, 0]) & (r[:, 2] > r[:, 1]) & (r[:, 3] > r[:, 2]) & (r[:, 5] > r[:, 4]) & (r[:, 3] - r[:, 0] < 10**8)
+    if not ok.any():
+        print(i, "no records")
+        continue
+    d = r[ok]
+    clk = (d[:, 2] - d[:, 1]) / (d[:, 5] - d[:, 4]) * 0.1
+    pre, loop, post = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]
+    buf2 = np.zeros(1024 * 4, dtype=np.uint64)
+    e.lib.flope_debug_read_ws(e.handle, buf2.ctypes.data_as(C.c_void_p), C.c_size_t(i * 1048576 + 65536), C.c_size_t(buf2.nbytes))
+    q = buf2.reshape(-1, 4).astype(np.int64)[: r.shape[0]][ok]
+    seg = [np.median(q[:, 0] - d[:, 0]), np.median(q[:, 1] - q[:, 0]), np.median(q[:, 2] - q[:, 1]), np.median(q[:, 3] - q[:, 2]), np.median(d[:, 1] - q[:, 3])]
+    print("          pre split: entry->first DMA %.0f | DMA issue + psrc %.0f | tables + acc init %.0f | wait + barrier %.0f | shortcut + first reads %.0f" % tuple(seg))
+    print(f"conv {i:2d}: {int(ok.sum()):4d} wg  pre {np.median(pre):7.0f}  loop {np.median(loop):8.0f}  post {np.median(post):7.0f}  "
+          f"clock {np.median(clk):.3f} GHz ({clk.min():.2f}-{clk.max():.2f})")
+e.close()
