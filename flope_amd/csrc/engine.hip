@@ -32,6 +32,9 @@ extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
 extern "C" int flope_conv_stag_init();
 extern "C" int flope_conv_gstag_init();
 extern "C" int flope_conv_w4_init();
+extern "C" int flope_conv_r4_init();
+extern "C" int flope_conv_r4_ok(const ConvP* p);
+extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream);
 extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, void* stream);
 extern "C" size_t flope_conv_w4_lds(int pt, int nbd);
 extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
@@ -94,7 +97,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_w4 = 6;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4 = 6;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -389,6 +392,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     if (s == 0) s = flope_conv_stag_init();
     if (s == 0) s = flope_conv_gstag_init();
     if (s == 0) s = flope_conv_w4_init();
+    if (s == 0) s = flope_conv_r4_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
   const size_t B = (size_t)max_batch;
@@ -514,6 +518,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
+  else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
   else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = (value >= 3 && value <= 6) ? value : 0; return prev; }
   else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "reslds")) { prev = e->opt_reslds; e->opt_reslds = value != 0; return prev; }
@@ -691,6 +696,14 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
                                           : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
+      // r03: layer 1 (64 -> 64 on the 56-wide map) on the 4-wave row-band kernel (conv_r4.hip)
+      if (c.stag == 2 && e->opt_r4 && c.nseg <= 1 && !(e->opt_dbg & 128) && flope_conv_r4_ok(&p)) {
+        fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
+        if ((e->opt_dbg & 64) && e->split_ws) p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
+        SMARK();
+        K_TRY(e, c.name.c_str(), flope_conv_r4_launch(&p, dt, gridb, stream));
+        continue;
+      }
       // split-K for small batches: with fewer tiles than half the CUs a tile's serial K loop (up to 72 double steps) is the
       // layer's latency; give every tile ksplit workgroups, each a share of the input channels.  A split pays its fp32
       // partial sums (128 KB per workgroup, written and read back) and a finalize launch, so the factor is chosen by a small
@@ -910,6 +923,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
     else if (c.stag == 3) snprintf(k, sizeof k, "conv_gstag_kernel<256x128,s2>");
     else if (w4_eligible(e, c)) snprintf(k, sizeof k, "conv_w4_kernel<256x128>");
+    else if (c.stag == 2 && e->opt_r4 && c.nseg <= 1 && c.cin == 64 && c.cout == 64 && c.wout == 56 && c.hout % 8 == 0) snprintf(k, sizeof k, "conv_r4_kernel<8rows x56>");
     else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
     s = c.name + "|" + k;
