@@ -26,6 +26,13 @@
 
 __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 12 ? 2 * (c - 4) + 1 : 2 * (c - 8)); }
 
+// Address table of a lane: xoff[t][pt] = LDS byte offset of its pixel fragment of pixel tile pt for tap t
+//   = (pi << 6) + ((g ^ ((sv >> 2) & 3)) << 4),  pi = pi0 + dy * pitch + dx,  sv = v0 + dy * W + dx   (conv_stag.hip, r03 image)
+//   and ((g ^ ((sv >> 2) & 3)) << 4) = ((sv << 2) ^ (g << 4)) & 0x30 = ((sv << 2) & 0x30) ^ (g << 4): everything but the last
+//   XOR is the same for the four k-slots g of a pixel column (and for both channel-half waves).
+// (r03: loading the table from memory instead -- precomputed per tile geometry class, 49 classes x 20 KiB per conv, 20 coalesced
+// 16-byte loads per lane -- was measured and dropped: the loads took 10-12 k cycles against 5 k for computing it, the tables do not
+// stay in L2 between tiles; step 1.116 vs 1.094 ms in same-run A/B.)
 // PT: 8 KB DMA rounds per patch buffer (4, 5 or 6).  NBD: double tiles in the weight ring (3 or 4; the DMA runs NBD - 1
 // double steps ahead of its consumer).  RES: residual input.  DSF: folded 1x1 stride-2 shortcut (no residual).
 template <typename T, int PT, bool RES, bool DSF, int NBD>
@@ -151,33 +158,44 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   W4_ISSUE_PATCH(patch_src, 0);
   W4_PSTAMP(1);
 
-  // fragment address table: xoff[t][pt] = LDS byte offset of this lane's pixel fragment of pixel tile pt for tap t
-  //   = (pi << 6) + ((g ^ ((sv >> 2) & 3)) << 4),  pi = pi0 + dy * pitch + dx,  sv = v0 + dy * W + dx
-  // in three vector instructions per entry (r03: the table was ~7 per entry, half of a 5 k-cycle prologue):
-  //   ((g ^ ((sv >> 2) & 3)) << 4) = ((sv << 2) ^ (g << 4)) & 0x30;  the tap terms are wave-uniform (scalar registers)
+  // Fragment address table xoff[t][pt] and output offsets ooff[pt].  Eight lanes of the workgroup -- the four k-slots g of a pixel
+  // column, in both channel-half waves -- need the same 8 x 9 offsets up to a final `^ (g << 4)` / `+ channel block`: each of the
+  // eight computes ONE pixel tile (a fastdiv chain + 9 entries, ~60 vector instructions instead of ~700) and they trade through 12 KB
+  // of LDS behind the weight ring (r03 stamps: the table was 3-5 k cycles of a 9-10 k-cycle prologue in which the matrix pipe idles).
   int xoff[9][MT];
-  unsigned ooff[MT];                                       // byte offset of this lane's 16 channels of pixel tile pt in the padded output
+  unsigned ooff[MT];
   bool ok[MT];
-  int tap_p[9], tap_v[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    tap_p[t] = ((t / 3) * pitch + (t % 3)) << 6;
-    tap_v[t] = ((t / 3) * p.Wo + (t % 3)) << 2;
-  }
-  const int g4 = g << 4;
-#pragma unroll
-  for (int pt = 0; pt < MT; ++pt) {
-    const int mm = m0 + wpx * 128 + pt * 16 + pcol;
-    ok[pt] = mm < mend;
+  {
+    char* const scr = smem + 2 * PATCH_B + NBD * DT_B + ((wpx * 16 + r16) * 8) * 48;     // [wpx][r16][pt][12 dwords]
+    const int ptm = wch * 4 + g;                                                          // the pixel tile this lane computes
+    const int HoWo_ = HoWo;
+    const int mm = m0 + wpx * 128 + ptm * 16 + pcol;
     const int m_ = min(mm, mend - 1);
-    // (24-bit multiplies: full-rate instructions, every factor here is far below 2^24)
-    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo);
+    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo_);
     const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);
     const int i_ = __mul24(b_, p.Hip) + ho_ - R0;
     const int pb = (__mul24(i_, pitch) + wo_) << 6, vb = (__mul24(i_, p.Wo) + wo_) << 2;
+    u32x4 e0, e1, e2;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) xoff[t][pt] = pb + tap_p[t] + (((vb + tap_v[t]) ^ g4) & 0x30);
-    ooff[pt] = (unsigned)((__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) + cb) * 2);
+    for (int t = 0; t < 9; ++t) {
+      const unsigned v = (unsigned)(pb + (((t / 3) * pitch + (t % 3)) << 6) + ((vb + (((t / 3) * p.Wo + (t % 3)) << 2)) & 0x30));
+      if (t < 4) e0[t] = v; else if (t < 8) e1[t - 4] = v; else e2[0] = v;
+    }
+    e2[1] = (unsigned)(__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) * 2);
+    e2[2] = 0u; e2[3] = 0u;
+    *(u32x4*)(scr + ptm * 48) = e0; *(u32x4*)(scr + ptm * 48 + 16) = e1; *(u32x4*)(scr + ptm * 48 + 32) = e2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS writes are done before the barrier lets the readers go (no vmcnt: the DMAs stay in flight)
+    W4_BARRIER();
+    const unsigned g4 = (unsigned)(g << 4);
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) {
+      const u32x4 a0 = *(const u32x4*)(scr + pt * 48), a1 = *(const u32x4*)(scr + pt * 48 + 16), a2 = *(const u32x4*)(scr + pt * 48 + 32);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { xoff[t][pt] = (int)(a0[t] ^ g4); xoff[4 + t][pt] = (int)(a1[t] ^ g4); }
+      xoff[8][pt] = (int)(a2[0] ^ g4);
+      ooff[pt] = a2[1] + (unsigned)(cb * 2);
+      ok[pt] = m0 + wpx * 128 + pt * 16 + pcol < mend;
+    }
   }
 
   // pin the tables in FRONT of the DMA wait (left alone, the compiler sinks these ~800 pure vector instructions behind the wait
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 template <typename T, bool RES, bool DSF, int NBD>
 static hipError_t w4_attr_pt() {
   hipError_t e = hipSuccess;
-#define A(PT_) if (e == hipSuccess && 2 * PT_ * 8192 + NBD * 16384 <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define A(PT_) if (e == hipSuccess && 2 * PT_ * 8192 + NBD * 16384 + 12288 <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A(4) A(5) A(6)
 #undef A
   return e;
@@ -441,8 +459,8 @@ static void w4_go_n(const ConvP& p, int pt, size_t lds, hipStream_t st) {
   else w4_go<T, false, false, NBD>(p, pt, lds, st);
 }
 
-// lds bytes needed: 2 * PT * 8192 + nbd * 16384
-extern "C" size_t flope_conv_w4_lds(int pt, int nbd) { return (size_t)2 * pt * 8192 + (size_t)nbd * 16384; }
+// lds bytes needed: 2 patch buffers, nbd double tiles of weights, 12 KB in which the lanes trade their shares of the address table
+extern "C" size_t flope_conv_w4_lds(int pt, int nbd) { return (size_t)2 * pt * 8192 + (size_t)nbd * 16384 + 12288; }
 
 // 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch), one tile per
 // workgroup: p->patch_rows_max = PT (4, 5 or 6), p->total_tiles = ceil(M / 256) * Cout / 128, p->w the conv_stag weight image.
