@@ -35,7 +35,12 @@ __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 1
 // stay in L2 between tiles; step 1.116 vs 1.094 ms in same-run A/B.)
 // PT: 8 KB DMA rounds per patch buffer (4, 5 or 6).  NBD: double tiles in the weight ring (3 or 4; the DMA runs NBD - 1
 // double steps ahead of its consumer).  RES: residual input.  DSF: folded 1x1 stride-2 shortcut (no residual).
-template <typename T, int PT, bool RES, bool DSF, int NBD>
+// PERS (no residual input): at most one workgroup per CU walks M tiles mt, mt + G, ... of its channel tile.  The step stream does
+// not stop at a tile boundary: the weight ring wraps to the start of the panel (= the next tile's first double tiles) and the
+// patch burst of double step 5 of a tile's last body fetches the NEXT tile's first half-chunk -- r03 stamps: of the 9-10 k cycles a
+// tile spends before its first MFMA, ~5 k are nothing but the flight time of its first DMAs; only the epilogue, the next tile's
+// address table (~1 k cycles) and the folded shortcut sit between two tiles.
+template <typename T, int PT, bool RES, bool DSF, int NBD, bool PERS>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
   constexpr int BM = 256, TILE_B = 128 * 64, DT_B = 2 * TILE_B, MT = 8, NT = 4;
@@ -43,19 +48,26 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   constexpr int PD = NBD - 1;                              // double tiles in flight ahead of the one being consumed
   constexpr int TGW = DT_B / 4096;                         // LDS-DMA ops per wave per double tile (4)
   constexpr int PW = 2 * PT;                               // ... per patch burst
-  static_assert(!(RES && DSF) && PT >= 4 && NBD >= 3 && NBD <= 6, "conv_w4 variants");
+  static_assert(!(RES && DSF) && !(RES && PERS) && PT >= 4 && NBD >= 3 && NBD <= 5, "conv_w4 variants");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;                                   // 2 patch buffers
   char* const Bs = smem + 2 * PATCH_B;                     // NBD double tiles of weights
+  // DSF: the shortcut's double tile of weights.  One tile per workgroup: the ring's last look-ahead slot, idle until the first
+  // body double step issues into it.  PERS: at a tile boundary every ring slot is in flight -> a slot of its own behind the ring.
+  constexpr int DSW_B = (PERS ? NBD : NBD - 1) * DT_B;
+  constexpr int SCR_B = 2 * PATCH_B + NBD * DT_B + (DSF && PERS ? DT_B : 0);   // 12 KB: address-table exchange
 
 #ifdef FLOPE_STAG_DBG
   // diagnostic build, dbg & 64: shader-clock stamps {entry, loop start, loop end, exit} + 100 MHz real time {loop start, loop end}
   // of wave 0, one record of 6 x uint64 per workgroup at p.split_ws (tools/clock_probe.py)
   const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
-  unsigned long long st_p[4] = {0, 0, 0, 0};
+  unsigned long long st_p[4] = {0, 0, 0, 0}, st_b[6] = {0, 0, 0, 0, 0, 0};
+  int st_tile = 0;
+#define W4_BSTAMP(i_) do { if (st_tile == 0) { __builtin_amdgcn_sched_barrier(0); st_b[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define W4_PSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); st_p[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define W4_PSTAMP(i_) do {} while (0)
+#define W4_BSTAMP(i_) do {} while (0)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,10 +84,18 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   const size_t rowB = (size_t)p.Wip * pixB;
   const int pitch = p.Wip + 2;                             // conflict-free patch image (conv_stag.hip, r03)
 
-  const int m0 = (lb / p.ntiles) * BM, mend = min(m0 + BM, p.M);
-  const int b0 = fastdiv(m0, p.mg_hw, p.sh_hw), ho0 = fastdiv(m0 - b0 * HoWo, p.mg_w, p.sh_w);
-  const int R0 = b0 * p.Hip + ho0;
-  const char* const patch_src = (const char*)p.in + (size_t)R0 * rowB;
+  int mt = lb / p.ntiles;                                  // this workgroup's current M tile
+  const int G_mt = gridDim.x / p.ntiles;                   // PERS: stride of its walk (the grid is a multiple of ntiles)
+  int m0, mend, R0;
+  const char* patch_src;
+#define W4_GEOM(mt_, m0_, mend_, R0_, src_)                                                                    \
+  do {                                                                                                         \
+    m0_ = (mt_) * BM; mend_ = min(m0_ + BM, p.M);                                                              \
+    const int b0_ = fastdiv(m0_, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0_ - b0_ * HoWo, p.mg_w, p.sh_w);          \
+    R0_ = b0_ * p.Hip + ho0_;                                                                                  \
+    src_ = (const char*)p.in + (size_t)R0_ * rowB;                                                             \
+  } while (0)
+  W4_GEOM(mt, m0, mend, R0, patch_src);
 
   const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + wave * 1024 + lane * 16;
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
@@ -128,19 +148,22 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                                         \
         GLDS16(dsrc[rr] + (2 * (j_) + t) * 64, Ps + PATCH_B + t * 16384 + (rr * 256 + wave * 64) * 16);        \
     _Pragma("unroll") for (int o = 0; o < TGW; ++o)                                                            \
-      GLDS16(dw_base + (size_t)(j_) * DT_B + o * 4096, Bs + (NBD - 1) * DT_B + o * 4096 + wave * 1024);        \
+      GLDS16(dw_base + (size_t)(j_) * DT_B + o * 4096, Bs + DSW_B + o * 4096 + wave * 1024);                   \
+  } while (0)
+#define W4_DS_SOURCES()   /* this lane's four gather sources of the current tile */                            \
+  do {                                                                                                         \
+    const size_t dpix = (size_t)p.ds_Cin * 2;                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                         \
+      const int q = rr * 256 + wave * 64 + lane, sl = q >> 2;                                                  \
+      const int m = min(m0 + sl, mend - 1);                                                                    \
+      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;                                         \
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;                                      \
+      dsrc[rr] = (const char*)p.ds_in + (((size_t)b_ * p.ds_Hip + 2 * ho_ + 1) * p.ds_Wip + 2 * wo_ + 1) * dpix + \
+                 (((q & 3) ^ ((sl >> 2) & 3)) << 4);                                                           \
+    }                                                                                                          \
   } while (0)
   if constexpr (DSF) {
-    const size_t dpix = (size_t)p.ds_Cin * 2;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int q = rr * 256 + wave * 64 + lane, sl = q >> 2;
-      const int m = min(m0 + sl, mend - 1);
-      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
-      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
-      dsrc[rr] = (const char*)p.ds_in + (((size_t)b_ * p.ds_Hip + 2 * ho_ + 1) * p.ds_Wip + 2 * wo_ + 1) * dpix +
-                 (((q & 3) ^ ((sl >> 2) & 3)) << 4);
-    }
+    W4_DS_SOURCES();
     dw_base = (const char*)p.ds_w + (size_t)ntile * (p.ds_Cin / 32) * TILE_B + wave * 1024 + lane * 16;
     W4_ISSUE_DS(0);
   }
@@ -165,38 +188,36 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   int xoff[9][MT];
   unsigned ooff[MT];
   bool ok[MT];
-  {
-    char* const scr = smem + 2 * PATCH_B + NBD * DT_B + ((wpx * 16 + r16) * 8) * 48;     // [wpx][r16][pt][12 dwords]
-    const int ptm = wch * 4 + g;                                                          // the pixel tile this lane computes
-    const int HoWo_ = HoWo;
-    const int mm = m0 + wpx * 128 + ptm * 16 + pcol;
-    const int m_ = min(mm, mend - 1);
-    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo_);
-    const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);
-    const int i_ = __mul24(b_, p.Hip) + ho_ - R0;
-    const int pb = (__mul24(i_, pitch) + wo_) << 6, vb = (__mul24(i_, p.Wo) + wo_) << 2;
-    u32x4 e0, e1, e2;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const unsigned v = (unsigned)(pb + (((t / 3) * pitch + (t % 3)) << 6) + ((vb + (((t / 3) * p.Wo + (t % 3)) << 2)) & 0x30));
-      if (t < 4) e0[t] = v; else if (t < 8) e1[t - 4] = v; else e2[0] = v;
-    }
-    e2[1] = (unsigned)(__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) * 2);
-    e2[2] = 0u; e2[3] = 0u;
-    *(u32x4*)(scr + ptm * 48) = e0; *(u32x4*)(scr + ptm * 48 + 16) = e1; *(u32x4*)(scr + ptm * 48 + 32) = e2;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS writes are done before the barrier lets the readers go (no vmcnt: the DMAs stay in flight)
-    W4_BARRIER();
-    const unsigned g4 = (unsigned)(g << 4);
-#pragma unroll
-    for (int pt = 0; pt < MT; ++pt) {
-      const u32x4 a0 = *(const u32x4*)(scr + pt * 48), a1 = *(const u32x4*)(scr + pt * 48 + 16), a2 = *(const u32x4*)(scr + pt * 48 + 32);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { xoff[t][pt] = (int)(a0[t] ^ g4); xoff[4 + t][pt] = (int)(a1[t] ^ g4); }
-      xoff[8][pt] = (int)(a2[0] ^ g4);
-      ooff[pt] = a2[1] + (unsigned)(cb * 2);
-      ok[pt] = m0 + wpx * 128 + pt * 16 + pcol < mend;
-    }
-  }
+#define W4_TABLE()                                                                                             \
+  do {                                                                                                         \
+    char* const scr = smem + SCR_B + ((wpx * 16 + r16) * 8) * 48;     /* [wpx][r16][pt][12 dwords] */          \
+    const int ptm = wch * 4 + g;                                      /* the pixel tile this lane computes */  \
+    const int mm = m0 + wpx * 128 + ptm * 16 + pcol;                                                           \
+    const int m_ = min(mm, mend - 1);                                                                          \
+    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo);                                 \
+    const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);                                \
+    const int i_ = __mul24(b_, p.Hip) + ho_ - R0;                                                              \
+    const int pb = (__mul24(i_, pitch) + wo_) << 6, vb = (__mul24(i_, p.Wo) + wo_) << 2;                       \
+    u32x4 e0, e1, e2;                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                            \
+      const unsigned v = (unsigned)(pb + (((t / 3) * pitch + (t % 3)) << 6) + ((vb + (((t / 3) * p.Wo + (t % 3)) << 2)) & 0x30)); \
+      if (t < 4) e0[t] = v; else if (t < 8) e1[t - 4] = v; else e2[0] = v;                                     \
+    }                                                                                                          \
+    e2[1] = (unsigned)(__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) * 2);           \
+    e2[2] = 0u; e2[3] = 0u;                                                                                    \
+    *(u32x4*)(scr + ptm * 48) = e0; *(u32x4*)(scr + ptm * 48 + 16) = e1; *(u32x4*)(scr + ptm * 48 + 32) = e2;  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the LDS writes are done before the barrier lets the readers go (no vmcnt: the DMAs stay in flight) */ \
+    W4_BARRIER();                                                                                              \
+    const unsigned g4 = (unsigned)(g << 4);                                                                    \
+    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
+      const u32x4 a0 = *(const u32x4*)(scr + pt * 48), a1 = *(const u32x4*)(scr + pt * 48 + 16), a2 = *(const u32x4*)(scr + pt * 48 + 32); \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) { xoff[t][pt] = (int)(a0[t] ^ g4); xoff[4 + t][pt] = (int)(a1[t] ^ g4); } \
+      xoff[8][pt] = (int)(a2[0] ^ g4);                                                                         \
+      ooff[pt] = a2[1] + (unsigned)(cb * 2);                                                                   \
+      ok[pt] = m0 + wpx * 128 + pt * 16 + pcol < mend;                                                         \
+    }                                                                                                          \
+  } while (0)
+  W4_TABLE();
 
   // pin the tables in FRONT of the DMA wait (left alone, the compiler sinks these ~800 pure vector instructions behind the wait
   // and the barrier, next to their first use -- the DMA flight time and the table time then add up instead of overlapping)
@@ -220,35 +241,34 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   W4_BARRIER();
   W4_PSTAMP(3);
 
+  int xds[DSF ? MT : 1];
   if constexpr (DSF) {
-    int xds[MT];
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
       const int sl = wpx * 128 + pt * 16 + pcol;
       xds[pt] = PATCH_B + (sl << 6) + ((g ^ ((sl >> 2) & 3)) << 4);
     }
-    for (int j = 0; j < p.ds_Cin / 64; ++j) {
-      if (j > 0) {
-        W4_ISSUE_DS(j);
-        W4_WAIT_VM(0);
-        W4_BARRIER();
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) wf[h][ct] = *(const frag*)(smem + wbase + (NBD - 1) * DT_B + h * TILE_B + ct * 1024);
-#pragma unroll
-        for (int pt = 0; pt < MT; ++pt) xf[h][pt] = *(const frag*)(smem + xds[pt] + h * 16384);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int pt = 0; pt < MT; ++pt)
-#pragma unroll
-          for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[h][ct], xf[h][pt], acc[pt][ct]);
-      W4_BARRIER();                                        // buffer 1 / the last ring slot are free again
-    }
   }
+  // the shortcut's double steps of the current tile; FIRST_: its first gather is already in LDS (issued with the prologue's DMAs)
+#define W4_DS_CHAIN(FIRST_)                                                                                    \
+  do {                                                                                                         \
+    for (int j = 0; j < p.ds_Cin / 64; ++j) {                                                                  \
+      if (!(FIRST_) || j > 0) {                                                                                \
+        W4_ISSUE_DS(j);                                                                                        \
+        W4_WAIT_VM(0);                                                                                         \
+        W4_BARRIER();                                                                                          \
+      }                                                                                                        \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                          \
+        _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) wf[h][ct] = *(const frag*)(smem + wbase + DSW_B + h * TILE_B + ct * 1024); \
+        _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) xf[h][pt] = *(const frag*)(smem + xds[pt] + h * 16384); \
+      }                                                                                                        \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                            \
+        _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                      \
+          _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[h][ct], xf[h][pt], acc[pt][ct]); \
+      W4_BARRIER();                                        /* buffer 1 / the shortcut's weight slot are free again */ \
+    }                                                                                                          \
+  } while (0)
+  if constexpr (DSF) W4_DS_CHAIN(true);
 
   // fragments of sub-step 0: double tile 0 (slot 0), half 0; patch buffer 0, tap 0
 #pragma unroll
@@ -294,6 +314,8 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   int slot_b = 0;                                          // byte offset of the ring slot of the double tile being consumed
   int hc = 0;                                              // first half-chunk of the current body
   int res_slot[2] = {0, 0};                                // ring slots (byte offsets) that received residual pieces of pixel tiles 4, 5 / 6, 7
+  bool after_epi = false;                                  // PERS: the epilogue stores of the previous tile are still in the VM queue
+  const char* n_patch_src = patch_src;                     // PERS: first half-chunk of the next tile's patch (else: unused prefetch)
 
   // double step D of a body: sub-steps u0 = 2 D, u1 = 2 D + 1 (tap u % 9 of half-chunk u / 9); the sub-step after u1 is 2 D + 2
   // (D = 8: the next body's first).  DMA pieces of the double step: 0 .. TGW - 1 = double tile D + PD into the slot PD ahead;
@@ -317,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
         unsigned ro_ = ooff[j_ >> 1]; asm volatile("" : "+v"(ro_));                                            \
         GLDS16((const char*)p.res + ro_ + (j_ & 1) * 64, Ps + (j_ * 256 + wave * 64) * 16);                    \
       } else {                                                                                                 \
-        GLDS16(patch_src + (hc + 2 < nhc ? (hc + 2) * 64 : 0) + psrc[j_], Ps + (j_ * 256 + wave * 64) * 16);   \
+        GLDS16((hc + 2 < nhc ? patch_src + (hc + 2) * 64 : n_patch_src) + psrc[j_], Ps + (j_ * 256 + wave * 64) * 16); \
       }                                                                                                        \
     }                                                                                                          \
   } while (0)
@@ -334,7 +356,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     int wof_ = wbase + slot_b, wofn_ = wbase + next_b_;                                                        \
     asm volatile("" : "+v"(wof_), "+v"(wofn_));                                                                \
     W4_SUB(0, 1, wof_ + TILE_B, U1_ / 9, U1_ % 9, 0, 0, W4_NODMA);                                             \
-    W4_WAIT_VM(WN_);                                                                                           \
+    /* PERS, first body behind a tile boundary: the 2 MT stores of the epilogue are younger than the double tiles issued before the \
+       boundary (D + 1 - PD < 0) and may stay in flight with them */                                           \
+    if (PERS && (D) <= PD - 2 && after_epi) W4_WAIT_VM(WN_ + 2 * MT); else W4_WAIT_VM(WN_);                    \
     W4_BARRIER();                                                                                              \
     int iss_b_ = slot_b + PD * DT_B; if (iss_b_ >= NBD * DT_B) iss_b_ -= NBD * DT_B;                           \
     const bool lastb_ = hc + 2 >= nhc;                                                                         \
@@ -347,17 +371,28 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 
 #ifdef FLOPE_STAG_DBG
   const unsigned long long st_l0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_l1 = 0, st_r1 = 0;
 #endif
+  for (;;) {
+  bool has_next = false;
+  int n_m0 = 0, n_mend = 0, n_R0 = 0;
+  if constexpr (PERS) {
+    has_next = mt + G_mt < p.mtiles;
+    if (has_next) W4_GEOM(mt + G_mt, n_m0, n_mend, n_R0, n_patch_src); else n_patch_src = patch_src;
+  }
   for (int hcp = 0; hcp < nbody; ++hcp) {
     W4_DSTEP(0); W4_DSTEP(1); W4_DSTEP(2); W4_DSTEP(3); W4_DSTEP(4); W4_DSTEP(5); W4_DSTEP(6); W4_DSTEP(7); W4_DSTEP(8);
     hc += 2;
+    after_epi = false;
   }
 
 #ifdef FLOPE_STAG_DBG
-  const unsigned long long st_l1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+  if (st_l1 == 0) { st_l1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime(); }
+  else if (st_b[5] == 0) st_b[5] = __builtin_amdgcn_s_memtime();      // end of the SECOND tile's loop
 #endif
+  W4_BSTAMP(0);
   // ---- epilogue: (+ residual) (ReLU) -> 16-bit padded NHWC straight from the accumulators
-  W4_WAIT_VM(0);                                           // look-ahead DMAs (and the residual rounds) have landed
+  if constexpr (!PERS) W4_WAIT_VM(0);                      // look-ahead DMAs (and the residual rounds) have landed
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) {
     float v[NT * 4];
@@ -391,6 +426,43 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       }
     }
   }
+  W4_BSTAMP(1);
+  if (!has_next) break;
+  // ---- PERS: next tile of this workgroup.  Its first half-chunk (burst of double step 5 of the last body) and its first double
+  // tiles are in LDS or in flight; what is younger than that burst in this wave's queue: the double tiles of double steps 6, 7, 8
+  // and the 2 MT stores just issued (a ragged tile stores fewer: drain, the static counts stay valid)
+  {
+    const bool full = mend - m0 == BM;
+    mt += G_mt; m0 = n_m0; mend = n_mend; R0 = n_R0; patch_src = n_patch_src;
+    if (full) W4_WAIT_VM(3 * TGW + 2 * MT); else W4_WAIT_VM(0);
+    W4_BSTAMP(2);
+    W4_TABLE();                                            // (its barrier also publishes the patch)
+    W4_BSTAMP(3);
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
+    after_epi = full;
+    if constexpr (DSF) {
+      W4_DS_SOURCES();
+      W4_DS_CHAIN(false);
+      after_epi = false;                                   // the chain's vmcnt(0) drained the queue
+    }
+    dn -= ND;
+    hc = 0;
+    int wof0_ = wbase + slot_b;
+    asm volatile("" : "+v"(wof0_));
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) wf[0][ct] = *(const frag*)(smem + wof0_ + ct * 1024);
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) xf[0][pt] = *(const frag*)(smem + xoff[0][pt]);
+    W4_BSTAMP(4);
+#ifdef FLOPE_STAG_DBG
+    ++st_tile;
+#endif
+  }
+  }   // tile walk
+  if constexpr (PERS) W4_WAIT_VM(0);                       // the wrapped-around look-ahead DMAs land before LDS is released
 #ifdef FLOPE_STAG_DBG
   if ((p.dbg & 64) && p.split_ws && wave == 0 && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -398,9 +470,17 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     d_[0] = st_e0; d_[1] = st_l0; d_[2] = st_l1; d_[3] = __builtin_amdgcn_s_memtime(); d_[4] = st_r0; d_[5] = st_r1;
     unsigned long long* q_ = (unsigned long long*)((char*)p.split_ws + 65536) + (size_t)blockIdx.x * 4;
     q_[0] = st_p[0]; q_[1] = st_p[1]; q_[2] = st_p[2]; q_[3] = st_p[3];
+    unsigned long long* b_ = (unsigned long long*)((char*)p.split_ws + 131072) + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 6; ++i) b_[i] = st_b[i];
+    b_[6] = st_l1;
   }
 #endif
 #undef W4_PSTAMP
+#undef W4_BSTAMP
+#undef W4_GEOM
+#undef W4_TABLE
+#undef W4_DS_SOURCES
+#undef W4_DS_CHAIN
 #undef W4_DSTEP
 #undef W4_ISSUE_DS
 #undef W4_DMA_PIECE
@@ -413,19 +493,24 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #undef W4_WAIT_VM
 }
 
-template <typename T, bool RES, bool DSF, int NBD>
+// own_ds_slot: persistent workgroups with a folded shortcut
+static constexpr size_t w4_lds_bytes(int pt, int nbd, bool own_ds_slot) { return (size_t)2 * pt * 8192 + (size_t)(nbd + (own_ds_slot ? 1 : 0)) * 16384 + 12288; }
+
+template <typename T, bool RES, bool DSF, int NBD, bool PERS>
 static hipError_t w4_attr_pt() {
   hipError_t e = hipSuccess;
-#define A(PT_) if (e == hipSuccess && 2 * PT_ * 8192 + NBD * 16384 + 12288 <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define A(PT_) if (e == hipSuccess && w4_lds_bytes(PT_, NBD, DSF && PERS) <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A(4) A(5) A(6)
 #undef A
   return e;
 }
 template <typename T, int NBD>
 static hipError_t w4_attr_n() {
-  hipError_t e = w4_attr_pt<T, false, false, NBD>();
-  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD>();
+  hipError_t e = w4_attr_pt<T, false, false, NBD, false>();
+  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD, false>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, false, NBD, true>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, true>();
   return e;
 }
 template <typename T>
@@ -433,7 +518,6 @@ static hipError_t w4_attr() {
   hipError_t e = w4_attr_n<T, 3>();
   if (e == hipSuccess) e = w4_attr_n<T, 4>();
   if (e == hipSuccess) e = w4_attr_n<T, 5>();
-  if (e == hipSuccess) e = w4_attr_n<T, 6>();
   return e;
 }
 
@@ -443,43 +527,47 @@ extern "C" int flope_conv_w4_init() {
   return (int)e;
 }
 
-template <typename T, bool RES, bool DSF, int NBD>
-static void w4_go(const ConvP& p, int pt, size_t lds, hipStream_t st) {
-  const dim3 grid(p.total_tiles), block(256);
+template <typename T, bool RES, bool DSF, int NBD, bool PERS>
+static void w4_go(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
+  const dim3 grid(grid_blocks), block(256);
   switch (pt) {
-    case 4: hipLaunchKernelGGL((conv_w4_kernel<T, 4, RES, DSF, NBD>), grid, block, lds, st, p); break;
-    case 5: hipLaunchKernelGGL((conv_w4_kernel<T, 5, RES, DSF, NBD>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((conv_w4_kernel<T, 6, RES, DSF, NBD>), grid, block, lds, st, p); break;
+    case 4: hipLaunchKernelGGL((conv_w4_kernel<T, 4, RES, DSF, NBD, PERS>), grid, block, lds, st, p); break;
+    case 5: hipLaunchKernelGGL((conv_w4_kernel<T, 5, RES, DSF, NBD, PERS>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_w4_kernel<T, 6, RES, DSF, NBD, PERS>), grid, block, lds, st, p); break;
   }
 }
 template <typename T, int NBD>
-static void w4_go_n(const ConvP& p, int pt, size_t lds, hipStream_t st) {
-  if (p.ds_in) w4_go<T, false, true, NBD>(p, pt, lds, st);
-  else if (p.res) w4_go<T, true, false, NBD>(p, pt, lds, st);
-  else w4_go<T, false, false, NBD>(p, pt, lds, st);
+static void w4_go_n(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
+  const bool pers = grid_blocks < p.total_tiles;
+  if (p.ds_in) { if (pers) w4_go<T, false, true, NBD, true>(p, pt, grid_blocks, lds, st); else w4_go<T, false, true, NBD, false>(p, pt, grid_blocks, lds, st); }
+  else if (p.res) w4_go<T, true, false, NBD, false>(p, pt, grid_blocks, lds, st);
+  else { if (pers) w4_go<T, false, false, NBD, true>(p, pt, grid_blocks, lds, st); else w4_go<T, false, false, NBD, false>(p, pt, grid_blocks, lds, st); }
 }
 
-// lds bytes needed: 2 patch buffers, nbd double tiles of weights, 12 KB in which the lanes trade their shares of the address table
-extern "C" size_t flope_conv_w4_lds(int pt, int nbd) { return (size_t)2 * pt * 8192 + (size_t)nbd * 16384 + 12288; }
+// lds bytes needed: 2 patch buffers, nbd double tiles of weights (+ 1 for the folded shortcut's), 12 KB in which the lanes trade
+// their shares of the address table
+extern "C" size_t flope_conv_w4_lds(int pt, int nbd, int dsf_persistent) { return w4_lds_bytes(pt, nbd, dsf_persistent != 0); }
 
-// 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch), one tile per
-// workgroup: p->patch_rows_max = PT (4, 5 or 6), p->total_tiles = ceil(M / 256) * Cout / 128, p->w the conv_stag weight image.
-// nbd = 3..6 double tiles in the weight ring (the DMA runs nbd - 1 double steps ahead).
-extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, void* stream) {
+// 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch):
+// p->patch_rows_max = PT (4, 5 or 6), p->mtiles = ceil(M / 256), p->total_tiles = mtiles * Cout / 128, p->w the conv_stag weight
+// image.  nbd = 3..5 double tiles in the weight ring (the DMA runs nbd - 1 double steps ahead).  grid_blocks = total_tiles: one
+// tile per workgroup; fewer (a multiple of Cout / 128, no residual input): persistent workgroups walk the M tiles.
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, void* stream) {
   const int pt = p->patch_rows_max;
-  if (p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 6 ||
-      (pt != 4 && pt != 5 && pt != 6) || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)))
+  if (p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 5 ||
+      (pt != 4 && pt != 5 && pt != 6) || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)) ||
+      grid_blocks < p->ntiles || grid_blocks > p->total_tiles || grid_blocks % p->ntiles || (p->res && grid_blocks != p->total_tiles) ||
+      p->total_tiles != p->mtiles * p->ntiles)
     return (int)hipErrorInvalidValue;
-  const size_t lds = flope_conv_w4_lds(pt, nbd);
+  const size_t lds = w4_lds_bytes(pt, nbd, p->ds_in != nullptr && grid_blocks < p->total_tiles);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
 #define GO(T)                                                                                                  \
   do {                                                                                                         \
     switch (nbd) {                                                                                             \
-      case 3: w4_go_n<T, 3>(*p, pt, lds, st); break;                                                           \
-      case 4: w4_go_n<T, 4>(*p, pt, lds, st); break;                                                           \
-      case 5: w4_go_n<T, 5>(*p, pt, lds, st); break;                                                           \
-      default: w4_go_n<T, 6>(*p, pt, lds, st); break;                                                          \
+      case 3: w4_go_n<T, 3>(*p, pt, grid_blocks, lds, st); break;                                              \
+      case 4: w4_go_n<T, 4>(*p, pt, grid_blocks, lds, st); break;                                              \
+      default: w4_go_n<T, 5>(*p, pt, grid_blocks, lds, st); break;                                             \
     }                                                                                                          \
   } while (0)
   if (dtype == 0) GO(bf16_t); else GO(f16_t);

@@ -35,8 +35,8 @@ extern "C" int flope_conv_w4_init();
 extern "C" int flope_conv_r4_init();
 extern "C" int flope_conv_r4_ok(const ConvP* p);
 extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream);
-extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, void* stream);
-extern "C" size_t flope_conv_w4_lds(int pt, int nbd);
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, void* stream);
+extern "C" size_t flope_conv_w4_lds(int pt, int nbd, int dsf);
 extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
@@ -97,7 +97,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4 = 6;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -520,6 +520,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
   else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = (value >= 3 && value <= 6) ? value : 0; return prev; }
+  else if (!strcmp(name, "w4grid")) { prev = e->opt_w4grid; e->opt_w4grid = value < 0 ? 0 : value; return prev; }
+  else if (!strcmp(name, "w4p")) { prev = e->opt_w4p; e->opt_w4p = value != 0; return prev; }
   else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "reslds")) { prev = e->opt_reslds; e->opt_reslds = value != 0; return prev; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -731,12 +733,21 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
       // r03: flat 256 x 128 tiles, one tile per workgroup, no split-K -> the 4-wave kernel (conv_w4.hip)
       if (w4_eligible(e, c) && ksp == 1 && gridb == p.total_tiles && !(e->opt_dbg & 128)) {
-        int nbd = e->opt_w4;                               // weight-ring depth asked for; the deepest that fits the CU's LDS
-        while (nbd > 3 && flope_conv_w4_lds(c.stag_patch_bytes, nbd) > kLdsMax) --nbd;
-        if (flope_conv_w4_lds(c.stag_patch_bytes, nbd) <= kLdsMax) {
+        // persistent workgroups (w4p; no residual input): this slice's share of the CUs, a multiple of the channel tiles
+        int gw = p.total_tiles;
+        if (e->opt_w4p && !p.res) {
+          gw = std::min(p.total_tiles, e->opt_w4grid > 0 ? e->opt_w4grid   // (tests: a small grid makes every workgroup walk several tiles)
+                                                   : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
+          gw -= gw % p.ntiles;
+          if (gw < p.ntiles) gw = p.ntiles;
+        }
+        const int dsf = (p.ds_in && gw < p.total_tiles) ? 1 : 0;       // a folded shortcut needs its own weight slot only there
+        int nbd = std::min(e->opt_w4, 5);                  // weight-ring depth asked for; the deepest that fits the CU's LDS
+        while (nbd > 3 && flope_conv_w4_lds(c.stag_patch_bytes, nbd, dsf) > kLdsMax) --nbd;
+        if (flope_conv_w4_lds(c.stag_patch_bytes, nbd, dsf) <= kLdsMax) {
           fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
           SMARK();
-          K_TRY(e, c.name.c_str(), flope_conv_w4_launch(&p, dt, nbd, stream));
+          K_TRY(e, c.name.c_str(), flope_conv_w4_launch(&p, dt, nbd, gw, stream));
           continue;
         }
       }
@@ -953,7 +964,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
     if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d %s 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, w4_eligible(e, c) ? "conv_w4" : "conv_stag", c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
     if (c.stag == 2 && c.nseg > 1) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x %d column segments of 64 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.nseg, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
-    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, std::min(e->opt_w4, (int)((kLdsMax - 2 * c.stag_patch_bytes * 8192) / 16384)))); s += line; continue; }
+    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, std::max(3, std::min(std::min(e->opt_w4, 5), (int)((kLdsMax - 12288 - 2 * c.stag_patch_bytes * 8192) / 16384))), 0)); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);

@@ -48,6 +48,14 @@ for i in (6, 7, 8, 11, 12, 13, 16, 17, 18):
     q = buf2.reshape(-1, 4).astype(np.int64)[: r.shape[0]][ok]
     seg = [np.median(q[:, 0] - d[:, 0]), np.median(q[:, 1] - q[:, 0]), np.median(q[:, 2] - q[:, 1]), np.median(q[:, 3] - q[:, 2]), np.median(d[:, 1] - q[:, 3])]
     print("          pre split: entry->first DMA %.0f | DMA issue + psrc %.0f | tables + acc init %.0f | wait + barrier %.0f | shortcut + first reads %.0f" % tuple(seg))
+    buf3 = np.zeros(1024 * 8, dtype=np.uint64)
+    e.lib.flope_debug_read_ws(e.handle, buf3.ctypes.data_as(C.c_void_p), C.c_size_t(i * 1048576 + 131072), C.c_size_t(buf3.nbytes))
+    bb = buf3.reshape(-1, 8).astype(np.int64)[: r.shape[0]][ok]
+    two = (bb[:, 4] > bb[:, 0]) & (bb[:, 5] > bb[:, 4])
+    if two.any():
+        t = bb[two]
+        print("          boundary (persistent, first): epilogue %.0f | wait next patch %.0f | table exchange %.0f | acc + shortcut + first reads %.0f | second tile loop %.0f   (%d wg)"
+              % (np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2] - t[:, 1]), np.median(t[:, 3] - t[:, 2]), np.median(t[:, 4] - t[:, 3]), np.median(t[:, 5] - t[:, 4]), int(two.sum())))
     print(f"conv {i:2d}: {int(ok.sum()):4d} wg  pre {np.median(pre):7.0f}  loop {np.median(loop):8.0f}  post {np.median(post):7.0f}  "
           f"clock {np.median(clk):.3f} GHz ({clk.min():.2f}-{clk.max():.2f})")
 e.close()
