@@ -20,9 +20,21 @@
 // stay on conv_stag.
 #include "common.h"
 
-#define GLDS16(gptr, lptr)                                                                         \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),          \
+// LDS-DMA as inline assembly, hidden from hipcc's wait-count pass.  While that pass knows of one outstanding flat-encoded access that
+// may land in LDS (its "pending flat" state; global_load_lds counts as one) it forces every wait it inserts to 0: lgkmcnt(0) in
+// front of each sub-step's first MFMA (instead of counting the younger fragment reads it may leave in flight) and vmcnt(0) at the
+// first use of any ordinary load.  This kernel counts its DMAs itself (W4_WAIT_VM); the "memory" clobber keeps every ds_read /
+// ds_write on its side of a DMA in program order.
+#pragma clang diagnostic ignored "-Winline-asm"
+#ifndef FLOPE_W4_ASM_DMA         // the compiler-visible form (default: measured 1.5-2.5 % faster per conv than the hidden one)
+#define GLDS16(gptr, lptr)                                                                                     \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#else
+#define GLDS16(gptr, lptr)                                                                                     \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"((const char*)(gptr)),   \
+               "s"((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lptr)) : "memory", "m0")
+#endif
 
 __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 12 ? 2 * (c - 4) + 1 : 2 * (c - 8)); }
 
@@ -103,7 +115,16 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   const int cb = ntile * 128 + wch * 64 + g * 8;
   const float* const bias_p = p.bias + cb;
 
-#define W4_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#ifdef FLOPE_W4_OLDWAIT
+#define W4_WAIT_PIN() do {} while (0)
+#else
+#define W4_WAIT_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define W4_WAIT_VM(n_)                                                                                         \
+  do {                                                                                                         \
+    W4_WAIT_PIN();                                         /* behind the sub-step's last MFMAs, not in front of them */ \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                                                  \
+  } while (0)
 #define W4_BARRIER()                                                                                           \
   do {                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -283,6 +304,15 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // them).  Program order IS the wanted order (the compiler keeps LDS-DMA and ds_read in program order: both touch LDS);
   // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.
 #define W4_NODMA(i_) do {} while (0)
+#ifndef FLOPE_W4_ASM_DMA
+#define W4_VMEM_GROUP(P_, NV_, KV_)                                                                            \
+  do {                                                                                                         \
+    if constexpr ((KV_) > 0 && (P_) * (KV_) < (NV_))                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x020, (((P_) + 1) * (KV_) <= (NV_) ? (KV_) : (NV_) - (P_) * (KV_)), 0); \
+  } while (0)
+#else
+#define W4_VMEM_GROUP(P_, NV_, KV_) do {} while (0)         /* an inline-assembly DMA stays where the program put it */
+#endif
 #define W4_GRP(P_, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                      \
   do {                                                                                                         \
     _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
@@ -299,8 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     if constexpr ((KV_) > 2 && (P_) * (KV_) + 2 < (NV_)) DMA_(((P_) * (KV_) + 2));                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                         \
     if constexpr ((P_) < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                 \
-    if constexpr ((KV_) > 0 && (P_) * (KV_) < (NV_))                                                           \
-      __builtin_amdgcn_sched_group_barrier(0x020, (((P_) + 1) * (KV_) <= (NV_) ? (KV_) : (NV_) - (P_) * (KV_)), 0); \
+    W4_VMEM_GROUP(P_, NV_, KV_);                                                                               \
   } while (0)
 #define W4_SUB(C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                          \
   do {                                                                                                         \
@@ -322,6 +351,13 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // then, at D = 0 and D = 5, the PW pieces of a patch burst.  RES, last body: the burst of D = 5 (the next tile's patch: unused)
   // and the double tiles of D = 7, 8 (they wrap to the start of the panel: unused) carry the tile's residual instead --
   // 8 + 4 + 4 pieces per lane, the 16 bytes each lane adds itself in the epilogue.
+#ifdef FLOPE_STAG_DBG      /* ablation (results wrong by construction): dbg & 1 = no weight DMA in the loop, dbg & 2 = no patch DMA */
+#define W4_ABL_W if (!(p.dbg & 1))
+#define W4_ABL_P if (!(p.dbg & 2))
+#else
+#define W4_ABL_W
+#define W4_ABL_P
+#endif
 #define W4_DMA_PIECE(i_)                                                                                       \
   do {                                                                                                         \
     if constexpr ((i_) < TGW) {                                                                                \
@@ -329,17 +365,17 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
         unsigned ro_ = ooff[4 + 2 * RS_ + (((i_) >> 1) & 1)]; asm volatile("" : "+v"(ro_));                    \
         GLDS16((const char*)p.res + ro_ + ((i_) & 1) * 64, Bs + iss_b_ + (i_) * 4096 + wave * 1024);           \
       } else {                                                                                                 \
-        GLDS16(b_base + (size_t)di_ * DT_B + (i_) * 4096, Bs + iss_b_ + (i_) * 4096 + wave * 1024);            \
+        W4_ABL_W GLDS16(b_base + (size_t)di_ * DT_B + (i_) * 4096, Bs + iss_b_ + (i_) * 4096 + wave * 1024);   \
       }                                                                                                        \
     } else {                                                                                                   \
       constexpr int j_ = (i_) - TGW < 0 ? 0 : ((i_) - TGW >= PW ? PW - 1 : (i_) - TGW);                        \
       if (D_ == 0) {                                                                                           \
-        GLDS16(patch_src + (hc + 1) * 64 + psrc[j_], Ps + PATCH_B + (j_ * 256 + wave * 64) * 16);              \
+        W4_ABL_P GLDS16(patch_src + (hc + 1) * 64 + psrc[j_], Ps + PATCH_B + (j_ * 256 + wave * 64) * 16);     \
       } else if (RES && lastb_ && j_ < 8) {                                                                    \
         unsigned ro_ = ooff[j_ >> 1]; asm volatile("" : "+v"(ro_));                                            \
         GLDS16((const char*)p.res + ro_ + (j_ & 1) * 64, Ps + (j_ * 256 + wave * 64) * 16);                    \
       } else {                                                                                                 \
-        GLDS16((hc + 2 < nhc ? patch_src + (hc + 2) * 64 : n_patch_src) + psrc[j_], Ps + (j_ * 256 + wave * 64) * 16); \
+        W4_ABL_P GLDS16((hc + 2 < nhc ? patch_src + (hc + 2) * 64 : n_patch_src) + psrc[j_], Ps + (j_ * 256 + wave * 64) * 16); \
       }                                                                                                        \
     }                                                                                                          \
   } while (0)
@@ -350,7 +386,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
        burst issued in the second sub-step of double step Dp in {0, 5} while D + 1 - PD <= Dp <= D - 1 */      \
     /* (PD >= 5: a burst of D = 5 would still be younger at the NEXT body's D = 0; not counted there -- the first body has none --   \
        which only makes that one wait stricter than it needs to be) */                                          \
-    constexpr int WN_ = TGW * (PD - 2) + ((((D) >= 1 && (D) <= PD - 1) || ((D) >= 6 && (D) <= PD + 4)) ? PW : 0); \
+    /* ... and only while that burst is not yet due: the burst of Dp = 0 is read from sub-step 8 on (behind barrier 3), the one \
+       of Dp = 5 from sub-step 17 on (behind barrier 8) */                                                     \
+    constexpr int WN_ = TGW * (PD - 2) + ((((D) >= 1 && (D) <= PD - 1 && (D) <= 2) || ((D) >= 6 && (D) <= PD + 4 && (D) <= 7)) ? PW : 0); \
     constexpr int NV_ = TGW + (((D) == 0 || (D) == 5) ? PW : 0), KV_ = (NV_ + 7) / 8;                          \
     const int next_b_ = slot_b + DT_B >= NBD * DT_B ? 0 : slot_b + DT_B;                                       \
     int wof_ = wbase + slot_b, wofn_ = wbase + next_b_;                                                        \
@@ -484,7 +522,10 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #undef W4_DSTEP
 #undef W4_ISSUE_DS
 #undef W4_DMA_PIECE
+#undef W4_ABL_W
+#undef W4_ABL_P
 #undef W4_NODMA
+#undef W4_VMEM_GROUP
 #undef W4_SUB
 #undef W4_GRP
 #undef W4_ISSUE_DT

@@ -24,7 +24,7 @@ for kv in (sys.argv[2].split(",") if len(sys.argv) > 2 else []):
     k, v = kv.split("=")
     e.set_option(k, int(v))
 e.load_state_dict(sd)
-e.set_option("dbg", 64)
+e.set_option("dbg", 64 | int(os.environ.get("ABL", 0)))   # ABL=1: no weight DMA in the loop, 2: no patch DMA (timing only)
 t0 = time.time()
 while time.time() - t0 < 2.5:
     for _ in range(50):
