@@ -77,9 +77,13 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   int st_tile = 0;
 #define W4_BSTAMP(i_) do { if (st_tile == 0) { __builtin_amdgcn_sched_barrier(0); st_b[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define W4_PSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); st_p[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // per double step of the LAST body: lane 2 D = clock in front of the DMA wait, lane 2 D + 1 = behind the barrier (one VGPR)
+  unsigned st_v = 0;
+#define W4_DSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); { const unsigned lo_ = (unsigned)__builtin_amdgcn_s_memtime(); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(st_v) : "s"(lo_), "n"(i_)); } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define W4_PSTAMP(i_) do {} while (0)
 #define W4_BSTAMP(i_) do {} while (0)
+#define W4_DSTAMP(i_) do {} while (0)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,6 +308,11 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // them).  Program order IS the wanted order (the compiler keeps LDS-DMA and ds_read in program order: both touch LDS);
   // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.
 #define W4_NODMA(i_) do {} while (0)
+#ifdef FLOPE_W4_LATE_DMA        // the sub-step's DMA pieces in its LAST MFMA groups (groups 6, 7 carry no fragment reads)
+#define W4_G0(NV_, KV_) (8 - ((NV_) + (KV_) - 1) / ((KV_) > 0 ? (KV_) : 1))
+#else
+#define W4_G0(NV_, KV_) 0
+#endif
 #ifndef FLOPE_W4_ASM_DMA
 #define W4_VMEM_GROUP(P_, NV_, KV_)                                                                            \
   do {                                                                                                         \
@@ -324,12 +333,13 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       xf[N_][2 * ((P_) - 2)] = *(const frag*)(smem + xoff[nt_][2 * ((P_) - 2)] + (nb_) * PATCH_B);             \
       xf[N_][2 * ((P_) - 2) + 1] = *(const frag*)(smem + xoff[nt_][2 * ((P_) - 2) + 1] + (nb_) * PATCH_B);     \
     }                                                                                                          \
-    if constexpr ((KV_) > 0 && (P_) * (KV_) + 0 < (NV_)) DMA_(((P_) * (KV_) + 0));                             \
-    if constexpr ((KV_) > 1 && (P_) * (KV_) + 1 < (NV_)) DMA_(((P_) * (KV_) + 1));                             \
-    if constexpr ((KV_) > 2 && (P_) * (KV_) + 2 < (NV_)) DMA_(((P_) * (KV_) + 2));                             \
+    constexpr int Q_ = (P_) - W4_G0(NV_, KV_);             /* the DMA group index of this MFMA group (< 0: none yet) */ \
+    if constexpr ((KV_) > 0 && Q_ >= 0 && Q_ * (KV_) + 0 < (NV_)) DMA_((Q_ * (KV_) + 0));                      \
+    if constexpr ((KV_) > 1 && Q_ >= 0 && Q_ * (KV_) + 1 < (NV_)) DMA_((Q_ * (KV_) + 1));                      \
+    if constexpr ((KV_) > 2 && Q_ >= 0 && Q_ * (KV_) + 2 < (NV_)) DMA_((Q_ * (KV_) + 2));                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                         \
     if constexpr ((P_) < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                 \
-    W4_VMEM_GROUP(P_, NV_, KV_);                                                                               \
+    if constexpr (Q_ >= 0) W4_VMEM_GROUP(Q_, NV_, KV_);                                                        \
   } while (0)
 #define W4_SUB(C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                          \
   do {                                                                                                         \
@@ -396,8 +406,10 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     W4_SUB(0, 1, wof_ + TILE_B, U1_ / 9, U1_ % 9, 0, 0, W4_NODMA);                                             \
     /* PERS, first body behind a tile boundary: the 2 MT stores of the epilogue are younger than the double tiles issued before the \
        boundary (D + 1 - PD < 0) and may stay in flight with them */                                           \
+    W4_DSTAMP(2 * (D));                                                                                        \
     if (PERS && (D) <= PD - 2 && after_epi) W4_WAIT_VM(WN_ + 2 * MT); else W4_WAIT_VM(WN_);                    \
     W4_BARRIER();                                                                                              \
+    W4_DSTAMP(2 * (D) + 1);                                                                                    \
     int iss_b_ = slot_b + PD * DT_B; if (iss_b_ >= NBD * DT_B) iss_b_ -= NBD * DT_B;                           \
     const bool lastb_ = hc + 2 >= nhc;                                                                         \
     const int di_ = dn < ND ? dn : dn - ND;                                                                    \
@@ -512,9 +524,11 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     for (int i = 0; i < 6; ++i) b_[i] = st_b[i];
     b_[6] = st_l1;
   }
+  if ((p.dbg & 64) && p.split_ws && wave == 0 && lane < 18) ((unsigned*)((char*)p.split_ws + 196608))[(size_t)blockIdx.x * 32 + lane] = st_v;
 #endif
 #undef W4_PSTAMP
 #undef W4_BSTAMP
+#undef W4_DSTAMP
 #undef W4_GEOM
 #undef W4_TABLE
 #undef W4_DS_SOURCES
@@ -525,6 +539,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #undef W4_ABL_W
 #undef W4_ABL_P
 #undef W4_NODMA
+#undef W4_G0
 #undef W4_VMEM_GROUP
 #undef W4_SUB
 #undef W4_GRP

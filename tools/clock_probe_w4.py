@@ -56,6 +56,14 @@ for i in (6, 7, 8, 11, 12, 13, 16, 17, 18):
         t = bb[two]
         print("          boundary (persistent, first): epilogue %.0f | wait next patch %.0f | table exchange %.0f | acc + shortcut + first reads %.0f | second tile loop %.0f   (%d wg)"
               % (np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2] - t[:, 1]), np.median(t[:, 3] - t[:, 2]), np.median(t[:, 4] - t[:, 3]), np.median(t[:, 5] - t[:, 4]), int(two.sum())))
+    buf4 = np.zeros(1024 * 32, dtype=np.uint32)
+    e.lib.flope_debug_read_ws(e.handle, buf4.ctypes.data_as(C.c_void_p), C.c_size_t(i * 1048576 + 196608), C.c_size_t(buf4.nbytes))
+    dv = buf4.reshape(-1, 32)[: r.shape[0]][ok].astype(np.int64)
+    if dv[:, 1].any():
+        wait = (dv[:, 1:18:2] - dv[:, 0:18:2]) & 0xffffffff          # per double step: DMA wait + barrier
+        work = (dv[:, 2:18:2] - dv[:, 1:17:2]) & 0xffffffff          # behind barrier D .. in front of wait D + 1: 64 MFMA (floor 1024)
+        print("          last body, per double step D=0..8: wait+barrier " + " ".join("%4d" % v for v in np.median(wait, axis=0)))
+        print("                                    B(D) + A(D+1) 64 MFMA " + " ".join("%4d" % v for v in np.median(work, axis=0)))
     print(f"conv {i:2d}: {int(ok.sum()):4d} wg  pre {np.median(pre):7.0f}  loop {np.median(loop):8.0f}  post {np.median(post):7.0f}  "
           f"clock {np.median(clk):.3f} GHz ({clk.min():.2f}-{clk.max():.2f})")
 e.close()
