@@ -5,6 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+(`--steps 32` -- or `--cfg4` -- with `--gpus 8` is exactly BASELINE configs[3]: 8 x 32 x 256 = 65,536 crops.)
+
 One step = one pass of the hot path over one batch: 256 synthetic 224x224x3 crops, 16-bit
 NHWC, already resident in HBM -> PoseResNet trunk (MFMA convs) -> fp32 head -> special
 Procrustes -> yaw-null + 4x4 pose assembly (BASELINE configs[1]).  Ranks own independent
@@ -86,9 +88,13 @@ def main():
     ap.add_argument("--dtype", default=os.environ.get("FLOPE_DTYPE", "f16"), choices=["f16", "bf16"])
     ap.add_argument("--crop", type=int, default=224)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--cfg4", action="store_true",
+                    help="BASELINE configs[3] exactly: 32 steps of 256 crops per GPU, i.e. 65,536 crops on --gpus 8 (same as --steps 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16/f16 measurement")
     args = ap.parse_args()
+    if args.cfg4:
+        args.steps, args.batch, args.crop = 32, 256, 224
 
     from flope_amd import distributed as D
     from flope_amd import engine as E
@@ -206,15 +212,18 @@ def main():
                            "step_frac_of_peak": round(value / world * eng.flops(1) / 1e12 / PEAK_TFLOPS, 4)}
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # figure is the committed rocprofv3 --pmc result for this same workload (profiles/r01_traffic.json)
-        # (profiles/r02_traffic.json, tied to the kernel sources by their digest: a different build => null)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            tr = tj["kernels"].get(dom)
-            if tr and (B, S, args.dtype) == (256, 224, "f16") and tj.get("source_digest") == source_digest():
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
-        except (OSError, ValueError, KeyError):
-            pass
+        # (profiles/r<NN>_traffic.json, tied to the kernel sources by their digest: a different build => null)
+        import glob
+        for tf_ in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")), reverse=True):   # newest round first
+            try:
+                tj = json.load(open(tf_))
+                tr = tj["kernels"].get(dom)
+                if tr and (B, S, args.dtype) == (256, 224, "f16") and tj.get("source_digest") == source_digest():
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tf_)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
         out["source_digest"] = source_digest()
         out["kernels_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
         # ---- parity of this very configuration against the oracle on a sample ---------------------

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // DSF: the shortcut's double tile of weights.  One tile per workgroup: the ring's last look-ahead slot, idle until the first
   // body double step issues into it.  PERS: at a tile boundary every ring slot is in flight -> a slot of its own behind the ring.
   constexpr int DSW_B = (PERS ? NBD : NBD - 1) * DT_B;
-  constexpr int SCR_B = 2 * PATCH_B + NBD * DT_B + (DSF && PERS ? DT_B : 0);   // 12 KB: address-table exchange
+  constexpr int SCR_B = 2 * PATCH_B + NBD * DT_B + (DSF && PERS ? DT_B : 0);   // 12.5 KB: address-table exchange
 
 #ifdef FLOPE_STAG_DBG
   // diagnostic build, dbg & 64: shader-clock stamps {entry, loop start, loop end, exit} + 100 MHz real time {loop start, loop end}
@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   bool ok[MT];
 #define W4_TABLE()                                                                                             \
   do {                                                                                                         \
-    char* const scr = smem + SCR_B + ((wpx * 16 + r16) * 8) * 48;     /* [wpx][r16][pt][12 dwords] */          \
+    /* [wpx][r16][pt][12 dwords], 400 B (25 bank quads, odd) per r16: the 16 pixel columns of a ds_read_b128 lane group land on \
+       16 different quads (at 384 B they fell on two: the reads below were 8-way conflicts, r03a counters) */   \
+    char* const scr = smem + SCR_B + (wpx * 16 + r16) * 400;                                                   \
     const int ptm = wch * 4 + g;                                      /* the pixel tile this lane computes */  \
     const int mm = m0 + wpx * 128 + ptm * 16 + pcol;                                                           \
     const int m_ = min(mm, mend - 1);                                                                          \
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 }
 
 // own_ds_slot: persistent workgroups with a folded shortcut
-static constexpr size_t w4_lds_bytes(int pt, int nbd, bool own_ds_slot) { return (size_t)2 * pt * 8192 + (size_t)(nbd + (own_ds_slot ? 1 : 0)) * 16384 + 12288; }
+static constexpr size_t w4_lds_bytes(int pt, int nbd, bool own_ds_slot) { return (size_t)2 * pt * 8192 + (size_t)(nbd + (own_ds_slot ? 1 : 0)) * 16384 + 12800; }
 
 template <typename T, bool RES, bool DSF, int NBD, bool PERS>
 static hipError_t w4_attr_pt() {

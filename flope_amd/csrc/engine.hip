@@ -26,6 +26,8 @@ extern "C" int flope_maxpool_launch(const PoolP* p, int dtype, void* stream);
 extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, int w, int C, int dtype, void* stream);
 extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* W1p, const float* b1, float* hidden, int B, int K, int N, void* stream);
 extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, const float* xyz, int nullify, float* Rt, void* stream);
+extern "C" int flope_fc2_procrustes_k4_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, const float* xyz, int nullify, float* Rt, void* stream);
+extern "C" int flope_avgpool_fc1_launch(const void* in, const float* W1p, const float* b1, float* feat, float* hidden, int B, int h, int w, int C, int N, int dtype, void* stream);
 extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
@@ -97,7 +99,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_head_fuse = 0, opt_fc2_k4 = 1, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -513,6 +515,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
+  else if (!strcmp(name, "head_fuse")) { prev = e->opt_head_fuse; e->opt_head_fuse = value != 0; return prev; }   // avgpool + fc.0 in one launch (bit-identical to the two)
+  else if (!strcmp(name, "fc2_k4")) { prev = e->opt_fc2_k4; e->opt_fc2_k4 = value != 0; return prev; }            // fc_rot: K split over the four waves of a workgroup per image
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
   else if (!strcmp(name, "stem_regpool")) { prev = e->opt_stem_regpool; e->opt_stem_regpool = value != 0; return prev; }
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
@@ -608,6 +612,13 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
 // persistent grids still take conv_stag at launch time)
 static bool w4_eligible(const flope_engine* e, const Conv& c) {
   return e->opt_w4 && !e->opt_persist && c.stag == 1 && c.cout >= 128 && e->opt_skew && c.stag_patch_bytes >= 4 && c.stag_patch_bytes <= 6;
+}
+
+// avgpool + fc.0 as one launch (pool_head.hip avgpool_fc1_kernel): 16-bit trunk, packed W1, 256 | backbone_out_dim, final map <= 64 px
+static bool head_fused(const flope_engine* e) {
+  if (!e->opt_head_fuse || !e->opt_fc1_packed || e->dtype == FLOPE_DT_F32 || !e->W1p || e->bod % 256 || e->final_buf < 0) return false;
+  const Buf& b = e->bufs[e->final_buf];
+  return b.h * b.w <= 64;
 }
 
 struct PoseOut { const float* xyz = nullptr; int nullify = 0; float* Rt = nullptr; };   // optional [B,16] pose assembly
@@ -765,15 +776,26 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
   }
   const Buf& bl = vb[e->final_buf];
   SMARK();
-  K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
-  SMARK();
-  K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->opt_fc1_packed ? e->W1p : nullptr, e->b1, hidden, batch, 512, e->bod, stream));
+  if (head_fused(e)) {
+    const int rc = flope_avgpool_fc1_launch(bl.ptr, e->W1p, e->b1, feat, hidden, batch, bl.h, bl.w, 512, e->bod, dt, stream);
+    if (rc != 1) return fail(e, FLOPE_EHIP, "avgpool+fc1: launch failed");
+  } else {
+    K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
+    SMARK();
+    K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->opt_fc1_packed ? e->W1p : nullptr, e->b1, hidden, batch, 512, e->bod, stream));
+  }
   if (head) {
     SMARK();
     float* r9 = (r9_dev ? r9_dev : e->r9_scratch) + (size_t)start * 9;
-    K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(hidden, e->W2, e->b2, r9, R_dev ? R_dev + (size_t)start * 9 : nullptr,
-                                                                batch, e->bod, po.xyz ? po.xyz + (size_t)start * 3 : nullptr, po.nullify,
-                                                                po.Rt ? po.Rt + (size_t)start * 16 : nullptr, stream));
+    float* Rp = R_dev ? R_dev + (size_t)start * 9 : nullptr;
+    const float* xyzp = po.xyz ? po.xyz + (size_t)start * 3 : nullptr;
+    float* Rtp = po.Rt ? po.Rt + (size_t)start * 16 : nullptr;
+    int k4 = 0;
+    if (e->opt_fc2_k4) {
+      k4 = flope_fc2_procrustes_k4_launch(hidden, e->W2, e->b2, r9, Rp, batch, e->bod, xyzp, po.nullify, Rtp, stream);
+      if (k4 < 0) return fail(e, FLOPE_EHIP, "fc_rot+procrustes: launch failed");
+    }
+    if (!k4) K_TRY(e, "fc_rot+procrustes", flope_fc2_procrustes_launch(hidden, e->W2, e->b2, r9, Rp, batch, e->bod, xyzp, po.nullify, Rtp, stream));
   }
   SMARK();
 #undef SMARK
@@ -889,10 +911,11 @@ extern "C" double flope_forward_flops(flope_handle e, int batch) {
   return 2.0 * macs * batch;
 }
 
-static int head_launches(const flope_engine* e) { return (e->opt_fuse_stem && e->dtype != FLOPE_DT_F32) ? 1 : 3; }
+static int head_launches(const flope_engine* e) { return (e->opt_fuse_stem && e->dtype != FLOPE_DT_F32) ? 1 : 3; }   // front of the trunk: input + stem + maxpool
+static int tail_launches(const flope_engine* e) { return head_fused(e) ? 2 : 3; }                                   // avgpool, fc.0, fc_rot + Procrustes
 extern "C" int flope_forward_launches(flope_handle e) {
   if (!e) return 0;
-  int n = (int)e->convs.size() + 3 + head_launches(e);
+  int n = (int)e->convs.size() + tail_launches(e) + head_launches(e);
   for (const Conv& c : e->convs) n -= c.folded;
   return n;
 }
@@ -915,7 +938,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
   for (size_t i = 0; i < e->convs.size(); ++i) if (!e->convs[i].folded) live.push_back((int)i);
   const int nc = (int)live.size();
   const int nh = head_launches(e);
-  if (idx < 0 || idx >= nc + 3 + nh) return fail(e, FLOPE_EINVAL, "flope_launch_info: bad index");
+  if (idx < 0 || idx >= nc + tail_launches(e) + nh) return fail(e, FLOPE_EINVAL, "flope_launch_info: bad index");
   const bool f32 = e->dtype == FLOPE_DT_F32;
   std::string s; double f = 0.0;
   if (nh == 1) {
@@ -944,8 +967,9 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
       s = c.name + "+shortcut|" + k;
       f += 2.0 * cd.hout * cd.wout * cd.cout * cd.cin;
     }
-  } else if (idx == 3 + nc) s = "avgpool|avgpool_kernel";
-  else if (idx == 4 + nc) { s = "fc1|fc1_kernel"; f = 2.0 * 512 * e->bod; }
+  } else if (head_fused(e) && idx == 3 + nc) { s = "avgpool+fc1|avgpool_fc1_kernel"; f = 2.0 * 512 * e->bod; }
+  else if (!head_fused(e) && idx == 3 + nc) s = "avgpool|avgpool_kernel";
+  else if (!head_fused(e) && idx == 4 + nc) { s = "fc1|fc1_kernel"; f = 2.0 * 512 * e->bod; }
   else { s = "fc_rot+procrustes|fc2_procrustes_kernel"; f = 2.0 * 9 * e->bod; }
   snprintf(name, name_cap, "%s", s.c_str());
   *flops = f * batch;
@@ -964,7 +988,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
     if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d %s 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, w4_eligible(e, c) ? "conv_w4" : "conv_stag", c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
     if (c.stag == 2 && c.nseg > 1) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x %d column segments of 64 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.nseg, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
-    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, std::max(3, std::min(std::min(e->opt_w4, 5), (int)((kLdsMax - 12288 - 2 * c.stag_patch_bytes * 8192) / 16384))), 0)); s += line; continue; }
+    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, std::max(3, std::min(std::min(e->opt_w4, 5), (int)((kLdsMax - 12800 - 2 * c.stag_patch_bytes * 8192) / 16384))), 0)); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);

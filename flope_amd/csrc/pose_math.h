@@ -53,10 +53,14 @@ FLOPE_HD inline void procrustes3x3_jacobi(const float* M, float* R) {
         }
       }
   }
-  int best = 0;
-  for (int i = 1; i < 4; ++i)
-    if (A[i][i] > A[best][best]) best = i;
-  double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
+  // column of the largest eigenvalue, picked with selects: a runtime index into A / V would put both arrays into scratch memory
+  double bv = A[0][0], w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const bool gt = A[i][i] > bv;
+    bv = gt ? A[i][i] : bv;
+    w = gt ? V[0][i] : w; x = gt ? V[1][i] : x; y = gt ? V[2][i] : y; z = gt ? V[3][i] : z;
+  }
   const double n = 1.0 / sqrt(w * w + x * x + y * y + z * z);
   w *= n; x *= n; y *= n; z *= n;
   R[0] = (float)(1.0 - 2.0 * (y * y + z * z));  R[1] = (float)(2.0 * (x * y - z * w));  R[2] = (float)(2.0 * (x * z + y * w));
@@ -73,6 +77,18 @@ FLOPE_HD inline void procrustes3x3_jacobi(const float* M, float* R) {
 // Returns false (caller falls back to Jacobi) when the top eigenvalue is not safely isolated.
 FLOPE_HD inline double det3(double a, double b, double c, double d, double e, double f, double g, double h, double i) {
   return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
+
+// minor(R, J) of a 4x4 with compile-time row / column: rows != R, columns != J in ascending order (the order of the runtime
+// gather this replaces -- same operands, same det3, same bits)
+template <int R, int J> FLOPE_HD inline double minor4(const double (&n)[4][4]) {
+  constexpr int a0 = R == 0 ? 1 : 0, a1 = R <= 1 ? 2 : 1, a2 = R <= 2 ? 3 : 2;
+  constexpr int b0 = J == 0 ? 1 : 0, b1 = J <= 1 ? 2 : 1, b2 = J <= 2 ? 3 : 2;
+  return det3(n[a0][b0], n[a0][b1], n[a0][b2], n[a1][b0], n[a1][b1], n[a1][b2], n[a2][b0], n[a2][b1], n[a2][b2]);
+}
+template <int R> FLOPE_HD inline void cofactor_row(const double (&n)[4][4], double* q) {
+  const double m0 = minor4<R, 0>(n), m1 = minor4<R, 1>(n), m2 = minor4<R, 2>(n), m3 = minor4<R, 3>(n);
+  q[0] = ((R + 0) & 1) ? -m0 : m0; q[1] = ((R + 1) & 1) ? -m1 : m1; q[2] = ((R + 2) & 1) ? -m2 : m2; q[3] = ((R + 3) & 1) ? -m3 : m3;
 }
 
 FLOPE_HD inline bool procrustes3x3_newton(const float* M, float* R) {
@@ -101,15 +117,19 @@ FLOPE_HD inline bool procrustes3x3_newton(const float* M, float* R) {
   }
   double l = (double)lf * (1.0 + 1e-6) + 1e-9;        // stay on the upper side for the monotone fp64 polish
   bool ok = false;
+  double dl_last = 1.0;
   for (int it = 0; it < 8; ++it) {
     const double l2 = l * l;
     const double pv = (l2 + c2) * l2 + c1 * l + c0, dv = (4.0 * l2 + 2.0 * c2) * l + c1;
     if (!(dv > 1e-9)) return false;                    // top eigenvalue (nearly) repeated: gauge-degenerate input
     const double dl = pv / dv;
-    l -= dl;
+    l -= dl; dl_last = dl;
     if (fabs(dl) <= 4e-16 * l) { ok = true; break; }
   }
-  if (!ok) return false;
+  // r03: 0.37 % of random inputs never met the 2-ulp test -- with P'(l*) ~ 0.1 the rounding noise of P (1e-16) is a step of
+  // 1e-15, forever -- and took the Jacobi fallback, whose ~10 us one lane then imposed on its whole launch.  Eight quadratic
+  // steps that end on a step <= 1e-13 l have converged to that noise floor (seven orders below the float32 result's own).
+  if (!ok && !(fabs(dl_last) <= 1e-13 * l)) return false;
   for (int i = 0; i < 4; ++i) n[i][i] -= l;
   // diagonal cofactors of the rank-3 matrix: pick the row with the largest one
   const double d0 = det3(n[1][1], n[1][2], n[1][3], n[2][1], n[2][2], n[2][3], n[3][1], n[3][2], n[3][3]);
@@ -121,19 +141,14 @@ FLOPE_HD inline bool procrustes3x3_newton(const float* M, float* R) {
   if (fabs(d2) > best) { best = fabs(d2); r = 2; }
   if (fabs(d3) > best) { best = fabs(d3); r = 3; }
   if (!(best > 1e-7)) return false;                    // eigen-gap too small for the adjugate to be trustworthy
-  // cofactor row r of (N - l I): q_j = (-1)^(r+j) minor(r, j)
+  // cofactor row r of (N - l I): q_j = (-1)^(r+j) minor(r, j).  One statically indexed instance per r (r03: with r as a runtime
+  // index the gather of the minors went through scratch memory -- a dozen dependent round trips, most of this function's 15 us)
   double q[4];
-  for (int j = 0; j < 4; ++j) {
-    double s[9]; int t = 0;
-    for (int a = 0; a < 4; ++a) {
-      if (a == r) continue;
-      for (int b = 0; b < 4; ++b) {
-        if (b == j) continue;
-        s[t++] = n[a][b];
-      }
-    }
-    const double mn = det3(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
-    q[j] = ((r + j) & 1) ? -mn : mn;
+  switch (r) {
+    case 0: cofactor_row<0>(n, q); break;
+    case 1: cofactor_row<1>(n, q); break;
+    case 2: cofactor_row<2>(n, q); break;
+    default: cofactor_row<3>(n, q); break;
   }
   double w = q[0], x = q[1], y = q[2], z = q[3];
   const double nn = 1.0 / sqrt(w * w + x * x + y * y + z * z);

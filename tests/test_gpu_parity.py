@@ -270,6 +270,32 @@ def test_fc1_packed_weights_equal_the_row_major_kernel(state_dict, B):
     e.close()
 
 
+@pytest.mark.parametrize("B,S", [(1, 96), (37, 96), (256, 224), (13, 256)])
+def test_fused_head_equals_the_three_launch_head(state_dict, B, S):
+    """r03: avgpool + fc.0 in one launch keeps avgpool_kernel's partial sums and fc1_packed_kernel's MFMA sequence: `feat` and
+    `hidden` are bit-identical to the unfused launches (also for batches that are not multiples of 8 and for an 8x8 final map).
+    fc_rot with K split over four waves sums in another (fixed) order: same rotations within float32 rounding, same bits from
+    run to run."""
+    torch.manual_seed(B)
+    x = torch.rand(B, S, S, 3).to(torch.float16).cuda()
+    e = _engine(state_dict, S, S, B, "f16")
+    e.set_option("head_fuse", 1); e.set_option("fc2_k4", 0)
+    n_fused = e.launches()
+    r9a, Ra = e.forward(x)
+    fa, ha = e.read_stage("feat", B).clone(), e.read_stage("hidden", B).clone()
+    assert e.set_option("head_fuse", 0) == 1
+    assert e.launches() == n_fused + 1
+    r9b, Rb = e.forward(x)
+    assert torch.equal(fa, e.read_stage("feat", B)) and torch.equal(ha, e.read_stage("hidden", B))
+    assert torch.equal(r9a, r9b) and torch.equal(Ra, Rb)
+    assert e.set_option("fc2_k4", 1) == 0                 # (the default)
+    r9c, Rc = e.forward(x)
+    r9d, Rd = e.forward(x)
+    assert torch.equal(r9c, r9d) and torch.equal(Rc, Rd)
+    assert (r9a - r9c).abs().max() <= 1e-5 * max(1.0, float(r9c.abs().max())) and (Ra - Rc).abs().max() <= 2e-5
+    e.close()
+
+
 @pytest.mark.parametrize("B", [131, 200, 255])
 def test_slice_split_is_invisible(state_dict, B):
     """The internal two-slice split (3/8 : 5/8 on multiples of 8 images, row-band grids proportional to the slice) must

@@ -3,7 +3,7 @@
 # FETCH_SIZE calibration, and the side benches.  Output under gpurun_out/$1 (default r02).
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -24,7 +24,7 @@ python tools/summarize_prof.py $OUT/kt $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
 python tools/summarize_prof.py $OUT/calib > $OUT/calib_summary.txt
 python tools/roofline_table.py $OUT > $OUT/roofline.md
 python tools/make_traffic_json.py $OUT > $OUT/traffic.json
-cp $OUT/traffic.json profiles/r02_traffic.json      # bench.py reads the committed file: same sources, same digest
+cp $OUT/traffic.json profiles/$(echo $TAG | sed -E "s/^(r[0-9]+).*/\\1/")_traffic.json      # bench.py reads the committed file (newest round first): same sources, same digest
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 16
 echo "bench done"
 python tools/bench_e2e.py yolo 4 16 31 > $OUT/e2e.txt 2>&1

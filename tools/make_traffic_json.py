@@ -18,6 +18,8 @@ d = sys.argv[1]
 
 
 def label(k):
+    if "conv_w4" in k: return "conv_w4_kernel<256x128>"
+    if "conv_r4" in k: return "conv_r4_kernel<8rows x56>"
     if "conv_stag" in k and "Li64E" in k: return "conv_stag_kernel<8rows x64>"
     if "conv_stag" in k: return "conv_stag_kernel<256x128>"
     if "conv_gstag" in k: return "conv_gstag_kernel<256x128,s2>"
