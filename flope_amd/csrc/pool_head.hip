@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict
   const int img0 = blockIdx.y * 32;
   const int KB = K >> 5, pitch = K + 4, k4 = K >> 2;
   const f32x4* wp = (const f32x4*)W1p + ((size_t)min(ntile, N / 16 - 1) * KB * 2) * 64 + lane;
-  constexpr int WPD = 4;                                    // weight K blocks in flight (issued before the feature staging)
+#ifndef FLOPE_FC1_WPD
+#define FLOPE_FC1_WPD 4
+#endif
+  constexpr int WPD = FLOPE_FC1_WPD;                        // weight K blocks in flight (issued before the feature staging)
   f32x4 wa[WPD][2];
 #pragma unroll
   for (int d = 0; d < WPD; ++d) { const int kb = min(d, KB - 1); wa[d][0] = wp[(size_t)kb * 128]; wa[d][1] = wp[(size_t)kb * 128 + 64]; }
