@@ -52,10 +52,13 @@ __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 1
 // patch burst of double step 5 of a tile's last body fetches the NEXT tile's first half-chunk -- r03 stamps: of the 9-10 k cycles a
 // tile spends before its first MFMA, ~5 k are nothing but the flight time of its first DMAs; only the epilogue, the next tile's
 // address table (~1 k cycles) and the folded shortcut sit between two tiles.
-template <typename T, int PT, bool RES, bool DSF, int NBD, bool PERS>
+template <typename T, int PT, bool RES, bool DSF, int NBD, bool PERS, int MT>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
-  constexpr int BM = 256, TILE_B = 128 * 64, DT_B = 2 * TILE_B, MT = 8, NT = 4;
+  // MT = pixel tiles of 16 per wave: 8 -> 256-pixel workgroup tiles; 7 -> 224 (r03c: 224 divides the 28 x 28, 14 x 14 and 7 x 7
+  // maps of a 224 x 224 crop batch -- no ragged last tile -- and 224-pixel tiles land closer under a whole number of rounds)
+  constexpr int BM = 2 * MT * 16, WPXB = MT * 16, TILE_B = 128 * 64, DT_B = 2 * TILE_B, NT = 4;
+  static_assert(MT == 7 || MT == 8, "conv_w4: 7 or 8 pixel tiles per wave");
   constexpr int PATCH_B = PT * 8192;
   constexpr int PD = NBD - 1;                              // double tiles in flight ahead of the one being consumed
   constexpr int TGW = DT_B / 4096;                         // LDS-DMA ops per wave per double tile (4)
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
        16 different quads (at 384 B they fell on two: the reads below were 8-way conflicts, r03a counters) */   \
     char* const scr = smem + SCR_B + (wpx * 16 + r16) * 400;                                                   \
     const int ptm = wch * 4 + g;                                      /* the pixel tile this lane computes */  \
-    const int mm = m0 + wpx * 128 + ptm * 16 + pcol;                                                           \
+    const int mm = m0 + wpx * WPXB + ptm * 16 + pcol;                                                          \
     const int m_ = min(mm, mend - 1);                                                                          \
     const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo);                                 \
     const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);                                \
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       _Pragma("unroll") for (int t = 0; t < 4; ++t) { xoff[t][pt] = (int)(a0[t] ^ g4); xoff[4 + t][pt] = (int)(a1[t] ^ g4); } \
       xoff[8][pt] = (int)(a2[0] ^ g4);                                                                         \
       ooff[pt] = a2[1] + (unsigned)(cb * 2);                                                                   \
-      ok[pt] = m0 + wpx * 128 + pt * 16 + pcol < mend;                                                         \
+      ok[pt] = m0 + wpx * WPXB + pt * 16 + pcol < mend;                                                        \
     }                                                                                                          \
   } while (0)
   W4_TABLE();
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   if constexpr (DSF) {
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
-      const int sl = wpx * 128 + pt * 16 + pcol;
+      const int sl = wpx * WPXB + pt * 16 + pcol;
       xds[pt] = PATCH_B + (sl << 6) + ((g ^ ((sl >> 2) & 3)) << 4);
     }
   }
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.
 #define W4_NODMA(i_) do {} while (0)
 #ifdef FLOPE_W4_LATE_DMA        // the sub-step's DMA pieces in its LAST MFMA groups (groups 6, 7 carry no fragment reads)
-#define W4_G0(NV_, KV_) (8 - ((NV_) + (KV_) - 1) / ((KV_) > 0 ? (KV_) : 1))
+#define W4_G0(NV_, KV_) (MT - ((NV_) + (KV_) - 1) / ((KV_) > 0 ? (KV_) : 1))
 #else
 #define W4_G0(NV_, KV_) 0
 #endif
@@ -326,22 +329,25 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #endif
 #define W4_GRP(P_, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                      \
   do {                                                                                                         \
-    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
-      acc[P_][ct] = Elem<T>::mfma(wf[C_][ct], xf[C_][P_], acc[P_][ct]);                                        \
-    if constexpr ((P_) < 2) {                                                                                  \
-      wf[N_][2 * (P_)] = *(const frag*)(smem + (wo_) + (2 * (P_)) * 1024);                                     \
-      wf[N_][2 * (P_) + 1] = *(const frag*)(smem + (wo_) + (2 * (P_) + 1) * 1024);                             \
-    } else if constexpr ((P_) < 6) {                                                                           \
-      xf[N_][2 * ((P_) - 2)] = *(const frag*)(smem + xoff[nt_][2 * ((P_) - 2)] + (nb_) * PATCH_B);             \
-      xf[N_][2 * ((P_) - 2) + 1] = *(const frag*)(smem + xoff[nt_][2 * ((P_) - 2) + 1] + (nb_) * PATCH_B);     \
+    if constexpr ((P_) < MT) {                             /* MT = 7: the eighth group does not exist */          \
+      _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                        \
+        acc[P_][ct] = Elem<T>::mfma(wf[C_][ct], xf[C_][P_], acc[P_][ct]);                                      \
+      constexpr int X0_ = 2 * ((P_) - 2), X1_ = 2 * ((P_) - 2) + 1;   /* this group's two pixel fragments of the next set */ \
+      if constexpr ((P_) < 2) {                                                                                \
+        wf[N_][2 * (P_)] = *(const frag*)(smem + (wo_) + (2 * (P_)) * 1024);                                   \
+        wf[N_][2 * (P_) + 1] = *(const frag*)(smem + (wo_) + (2 * (P_) + 1) * 1024);                           \
+      } else if constexpr ((P_) < 6) {                                                                         \
+        xf[N_][X0_] = *(const frag*)(smem + xoff[nt_][X0_] + (nb_) * PATCH_B);                                 \
+        if constexpr (X1_ < MT) xf[N_][X1_] = *(const frag*)(smem + xoff[nt_][X1_] + (nb_) * PATCH_B);         \
+      }                                                                                                        \
+      constexpr int Q_ = (P_) - W4_G0(NV_, KV_);           /* the DMA group index of this MFMA group (< 0: none yet) */ \
+      if constexpr ((KV_) > 0 && Q_ >= 0 && Q_ * (KV_) + 0 < (NV_)) DMA_((Q_ * (KV_) + 0));                    \
+      if constexpr ((KV_) > 1 && Q_ >= 0 && Q_ * (KV_) + 1 < (NV_)) DMA_((Q_ * (KV_) + 1));                    \
+      if constexpr ((KV_) > 2 && Q_ >= 0 && Q_ * (KV_) + 2 < (NV_)) DMA_((Q_ * (KV_) + 2));                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                       \
+      if constexpr ((P_) < 6) __builtin_amdgcn_sched_group_barrier(0x100, ((P_) >= 2 && X1_ >= MT) ? 1 : 2, 0); \
+      if constexpr (Q_ >= 0) W4_VMEM_GROUP(Q_, NV_, KV_);                                                      \
     }                                                                                                          \
-    constexpr int Q_ = (P_) - W4_G0(NV_, KV_);             /* the DMA group index of this MFMA group (< 0: none yet) */ \
-    if constexpr ((KV_) > 0 && Q_ >= 0 && Q_ * (KV_) + 0 < (NV_)) DMA_((Q_ * (KV_) + 0));                      \
-    if constexpr ((KV_) > 1 && Q_ >= 0 && Q_ * (KV_) + 1 < (NV_)) DMA_((Q_ * (KV_) + 1));                      \
-    if constexpr ((KV_) > 2 && Q_ >= 0 && Q_ * (KV_) + 2 < (NV_)) DMA_((Q_ * (KV_) + 2));                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                         \
-    if constexpr ((P_) < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                 \
-    if constexpr (Q_ >= 0) W4_VMEM_GROUP(Q_, NV_, KV_);                                                        \
   } while (0)
 #define W4_SUB(C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                          \
   do {                                                                                                         \
@@ -373,8 +379,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #define W4_DMA_PIECE(i_)                                                                                       \
   do {                                                                                                         \
     if constexpr ((i_) < TGW) {                                                                                \
-      if (RES && lastb_ && (D_ == 7 || D_ == 8)) {                                                             \
-        unsigned ro_ = ooff[4 + 2 * RS_ + (((i_) >> 1) & 1)]; asm volatile("" : "+v"(ro_));                    \
+      constexpr int rpt_ = 4 + 2 * RS_ + (((i_) >> 1) & 1);   /* the pixel tile whose residual rides here (MT = 7: none for 7) */ \
+      if (RES && lastb_ && (D_ == 7 || D_ == 8) && rpt_ < MT) {                                                \
+        unsigned ro_ = ooff[rpt_ < MT ? rpt_ : 0]; asm volatile("" : "+v"(ro_));                               \
         GLDS16((const char*)p.res + ro_ + ((i_) & 1) * 64, Bs + iss_b_ + (i_) * 4096 + wave * 1024);           \
       } else {                                                                                                 \
         W4_ABL_W GLDS16(b_base + (size_t)di_ * DT_B + (i_) * 4096, Bs + iss_b_ + (i_) * 4096 + wave * 1024);   \
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     /* ... and only while that burst is not yet due: the burst of Dp = 0 is read from sub-step 8 on (behind barrier 3), the one \
        of Dp = 5 from sub-step 17 on (behind barrier 8) */                                                     \
     constexpr int WN_ = TGW * (PD - 2) + ((((D) >= 1 && (D) <= PD - 1 && (D) <= 2) || ((D) >= 6 && (D) <= PD + 4 && (D) <= 7)) ? PW : 0); \
-    constexpr int NV_ = TGW + (((D) == 0 || (D) == 5) ? PW : 0), KV_ = (NV_ + 7) / 8;                          \
+    constexpr int NV_ = TGW + (((D) == 0 || (D) == 5) ? PW : 0), KV_ = (NV_ + MT - 1) / MT;                    \
     const int next_b_ = slot_b + DT_B >= NBD * DT_B ? 0 : slot_b + DT_B;                                       \
     int wof_ = wbase + slot_b, wofn_ = wbase + next_b_;                                                        \
     asm volatile("" : "+v"(wof_), "+v"(wofn_));                                                                \
@@ -554,21 +561,24 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 // own_ds_slot: persistent workgroups with a folded shortcut
 static constexpr size_t w4_lds_bytes(int pt, int nbd, bool own_ds_slot) { return (size_t)2 * pt * 8192 + (size_t)(nbd + (own_ds_slot ? 1 : 0)) * 16384 + 12800; }
 
-template <typename T, bool RES, bool DSF, int NBD, bool PERS>
+template <typename T, bool RES, bool DSF, int NBD, bool PERS, int MT>
 static hipError_t w4_attr_pt() {
   hipError_t e = hipSuccess;
-#define A(PT_) if (e == hipSuccess && w4_lds_bytes(PT_, NBD, DSF && PERS) <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define A(PT_) if (e == hipSuccess && w4_lds_bytes(PT_, NBD, DSF && PERS) <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD, PERS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A(4) A(5) A(6)
 #undef A
   return e;
 }
 template <typename T, int NBD>
-static hipError_t w4_attr_n() {
-  hipError_t e = w4_attr_pt<T, false, false, NBD, false>();
-  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD, false>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, false, NBD, true>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, true>();
+static hipError_t w4_attr_n() {       // (224-pixel tiles: one tile per workgroup only)
+  hipError_t e = w4_attr_pt<T, false, false, NBD, false, 8>();
+  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD, false, 8>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false, 8>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, false, NBD, true, 8>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, true, 8>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, false, NBD, false, 7>();
+  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD, false, 7>();
+  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false, 7>();
   return e;
 }
 template <typename T>
@@ -585,21 +595,25 @@ extern "C" int flope_conv_w4_init() {
   return (int)e;
 }
 
-template <typename T, bool RES, bool DSF, int NBD, bool PERS>
+template <typename T, bool RES, bool DSF, int NBD, bool PERS, int MT>
 static void w4_go(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
   const dim3 grid(grid_blocks), block(256);
   switch (pt) {
-    case 4: hipLaunchKernelGGL((conv_w4_kernel<T, 4, RES, DSF, NBD, PERS>), grid, block, lds, st, p); break;
-    case 5: hipLaunchKernelGGL((conv_w4_kernel<T, 5, RES, DSF, NBD, PERS>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((conv_w4_kernel<T, 6, RES, DSF, NBD, PERS>), grid, block, lds, st, p); break;
+    case 4: hipLaunchKernelGGL((conv_w4_kernel<T, 4, RES, DSF, NBD, PERS, MT>), grid, block, lds, st, p); break;
+    case 5: hipLaunchKernelGGL((conv_w4_kernel<T, 5, RES, DSF, NBD, PERS, MT>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((conv_w4_kernel<T, 6, RES, DSF, NBD, PERS, MT>), grid, block, lds, st, p); break;
   }
 }
 template <typename T, int NBD>
-static void w4_go_n(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
+static void w4_go_n(const ConvP& p, int pt, int grid_blocks, int mt, size_t lds, hipStream_t st) {
   const bool pers = grid_blocks < p.total_tiles;
-  if (p.ds_in) { if (pers) w4_go<T, false, true, NBD, true>(p, pt, grid_blocks, lds, st); else w4_go<T, false, true, NBD, false>(p, pt, grid_blocks, lds, st); }
-  else if (p.res) w4_go<T, true, false, NBD, false>(p, pt, grid_blocks, lds, st);
-  else { if (pers) w4_go<T, false, false, NBD, true>(p, pt, grid_blocks, lds, st); else w4_go<T, false, false, NBD, false>(p, pt, grid_blocks, lds, st); }
+  if (mt == 7) {
+    if (p.ds_in) w4_go<T, false, true, NBD, false, 7>(p, pt, grid_blocks, lds, st);
+    else if (p.res) w4_go<T, true, false, NBD, false, 7>(p, pt, grid_blocks, lds, st);
+    else w4_go<T, false, false, NBD, false, 7>(p, pt, grid_blocks, lds, st);
+  } else if (p.ds_in) { if (pers) w4_go<T, false, true, NBD, true, 8>(p, pt, grid_blocks, lds, st); else w4_go<T, false, true, NBD, false, 8>(p, pt, grid_blocks, lds, st); }
+  else if (p.res) w4_go<T, true, false, NBD, false, 8>(p, pt, grid_blocks, lds, st);
+  else { if (pers) w4_go<T, false, false, NBD, true, 8>(p, pt, grid_blocks, lds, st); else w4_go<T, false, false, NBD, false, 8>(p, pt, grid_blocks, lds, st); }
 }
 
 // lds bytes needed: 2 patch buffers, nbd double tiles of weights (+ 1 for the folded shortcut's), 12 KB in which the lanes trade
@@ -607,12 +621,13 @@ static void w4_go_n(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStre
 extern "C" size_t flope_conv_w4_lds(int pt, int nbd, int dsf_persistent) { return w4_lds_bytes(pt, nbd, dsf_persistent != 0); }
 
 // 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch):
-// p->patch_rows_max = PT (4, 5 or 6), p->mtiles = ceil(M / 256), p->total_tiles = mtiles * Cout / 128, p->w the conv_stag weight
+// mt = 8 / 7 pixel tiles per wave = 256 / 224-pixel workgroup tiles; p->patch_rows_max = PT (4, 5 or 6: the patch of such a tile),
+// p->mtiles = ceil(M / (32 mt)), p->total_tiles = mtiles * Cout / 128, p->w the conv_stag weight
 // image.  nbd = 3..5 double tiles in the weight ring (the DMA runs nbd - 1 double steps ahead).  grid_blocks = total_tiles: one
-// tile per workgroup; fewer (a multiple of Cout / 128, no residual input): persistent workgroups walk the M tiles.
-extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, void* stream) {
+// tile per workgroup; fewer (a multiple of Cout / 128, no residual input, mt = 8): persistent workgroups walk the M tiles.
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, int mt, void* stream) {
   const int pt = p->patch_rows_max;
-  if (p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 5 ||
+  if ((mt != 7 && mt != 8) || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || (mt == 7 && grid_blocks != p->total_tiles) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 5 ||
       (pt != 4 && pt != 5 && pt != 6) || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)) ||
       grid_blocks < p->ntiles || grid_blocks > p->total_tiles || grid_blocks % p->ntiles || (p->res && grid_blocks != p->total_tiles) ||
       p->total_tiles != p->mtiles * p->ntiles)
@@ -623,9 +638,9 @@ extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid
 #define GO(T)                                                                                                  \
   do {                                                                                                         \
     switch (nbd) {                                                                                             \
-      case 3: w4_go_n<T, 3>(*p, pt, grid_blocks, lds, st); break;                                              \
-      case 4: w4_go_n<T, 4>(*p, pt, grid_blocks, lds, st); break;                                              \
-      default: w4_go_n<T, 5>(*p, pt, grid_blocks, lds, st); break;                                             \
+      case 3: w4_go_n<T, 3>(*p, pt, grid_blocks, mt, lds, st); break;                                          \
+      case 4: w4_go_n<T, 4>(*p, pt, grid_blocks, mt, lds, st); break;                                          \
+      default: w4_go_n<T, 5>(*p, pt, grid_blocks, mt, lds, st); break;                                         \
     }                                                                                                          \
   } while (0)
   if (dtype == 0) GO(bf16_t); else GO(f16_t);
