@@ -56,9 +56,10 @@ template <typename T, int PT, bool RES, bool DSF, int NBD, bool PERS, int MT>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
   // MT = pixel tiles of 16 per wave: 8 -> 256-pixel workgroup tiles; 7 -> 224 (r03c: 224 divides the 28 x 28, 14 x 14 and 7 x 7
-  // maps of a 224 x 224 crop batch -- no ragged last tile -- and 224-pixel tiles land closer under a whole number of rounds)
+  // maps of a 224 x 224 crop batch -- no ragged last tile -- and 224-pixel tiles land closer under a whole number of rounds);
+  // 6, 5, 4 -> 192, 160, 128: launches of fewer than ~200 tiles (layer 4, batch slices) fill more of the chip with smaller ones
   constexpr int BM = 2 * MT * 16, WPXB = MT * 16, TILE_B = 128 * 64, DT_B = 2 * TILE_B, NT = 4;
-  static_assert(MT == 7 || MT == 8, "conv_w4: 7 or 8 pixel tiles per wave");
+  static_assert(MT >= 4 && MT <= 8, "conv_w4: 4..8 pixel tiles per wave");
   constexpr int PATCH_B = PT * 8192;
   constexpr int PD = NBD - 1;                              // double tiles in flight ahead of the one being consumed
   constexpr int TGW = DT_B / 4096;                         // LDS-DMA ops per wave per double tile (4)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
         wf[N_][2 * (P_)] = *(const frag*)(smem + (wo_) + (2 * (P_)) * 1024);                                   \
         wf[N_][2 * (P_) + 1] = *(const frag*)(smem + (wo_) + (2 * (P_) + 1) * 1024);                           \
       } else if constexpr ((P_) < 6) {                                                                         \
-        xf[N_][X0_] = *(const frag*)(smem + xoff[nt_][X0_] + (nb_) * PATCH_B);                                 \
+        if constexpr (X0_ < MT) xf[N_][X0_] = *(const frag*)(smem + xoff[nt_][X0_] + (nb_) * PATCH_B);         \
         if constexpr (X1_ < MT) xf[N_][X1_] = *(const frag*)(smem + xoff[nt_][X1_] + (nb_) * PATCH_B);         \
       }                                                                                                        \
       constexpr int Q_ = (P_) - W4_G0(NV_, KV_);           /* the DMA group index of this MFMA group (< 0: none yet) */ \
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       if constexpr ((KV_) > 1 && Q_ >= 0 && Q_ * (KV_) + 1 < (NV_)) DMA_((Q_ * (KV_) + 1));                    \
       if constexpr ((KV_) > 2 && Q_ >= 0 && Q_ * (KV_) + 2 < (NV_)) DMA_((Q_ * (KV_) + 2));                    \
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                       \
-      if constexpr ((P_) < 6) __builtin_amdgcn_sched_group_barrier(0x100, ((P_) >= 2 && X1_ >= MT) ? 1 : 2, 0); \
+      constexpr int NR_ = (P_) < 2 ? 2 : ((P_) < 6 ? (X0_ < MT ? 1 : 0) + (X1_ < MT ? 1 : 0) : 0);   /* reads of this group */ \
+      if constexpr (NR_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, NR_, 0);                              \
       if constexpr (Q_ >= 0) W4_VMEM_GROUP(Q_, NV_, KV_);                                                      \
     }                                                                                                          \
   } while (0)
@@ -581,11 +583,29 @@ static hipError_t w4_attr_n() {       // (224-pixel tiles: one tile per workgrou
   if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false, 7>();
   return e;
 }
+// 4..6 pixel tiles per wave: 4 patch rounds, the 5-deep ring only
+template <typename T, int MT>
+static hipError_t w4_attr_small() {
+  hipError_t e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, 4, false, false, 5, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, 4, true, false, 5, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, 4, false, true, 5, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
+}
+template <typename T, int MT>
+static void w4_go_small(const ConvP& p, int grid_blocks, size_t lds, hipStream_t st) {
+  const dim3 grid(grid_blocks), block(256);
+  if (p.ds_in) hipLaunchKernelGGL((conv_w4_kernel<T, 4, false, true, 5, false, MT>), grid, block, lds, st, p);
+  else if (p.res) hipLaunchKernelGGL((conv_w4_kernel<T, 4, true, false, 5, false, MT>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((conv_w4_kernel<T, 4, false, false, 5, false, MT>), grid, block, lds, st, p);
+}
 template <typename T>
 static hipError_t w4_attr() {
   hipError_t e = w4_attr_n<T, 3>();
   if (e == hipSuccess) e = w4_attr_n<T, 4>();
   if (e == hipSuccess) e = w4_attr_n<T, 5>();
+  if (e == hipSuccess) e = w4_attr_small<T, 4>();
+  if (e == hipSuccess) e = w4_attr_small<T, 5>();
+  if (e == hipSuccess) e = w4_attr_small<T, 6>();
   return e;
 }
 
@@ -621,13 +641,14 @@ static void w4_go_n(const ConvP& p, int pt, int grid_blocks, int mt, size_t lds,
 extern "C" size_t flope_conv_w4_lds(int pt, int nbd, int dsf_persistent) { return w4_lds_bytes(pt, nbd, dsf_persistent != 0); }
 
 // 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch):
-// mt = 8 / 7 pixel tiles per wave = 256 / 224-pixel workgroup tiles; p->patch_rows_max = PT (4, 5 or 6: the patch of such a tile),
+// mt = 8 .. 4 pixel tiles per wave = 256 .. 128-pixel workgroup tiles (below 7: pt = 4 and nbd = 5 only); p->patch_rows_max = PT (4, 5 or 6: the patch of such a tile),
 // p->mtiles = ceil(M / (32 mt)), p->total_tiles = mtiles * Cout / 128, p->w the conv_stag weight
 // image.  nbd = 3..5 double tiles in the weight ring (the DMA runs nbd - 1 double steps ahead).  grid_blocks = total_tiles: one
 // tile per workgroup; fewer (a multiple of Cout / 128, no residual input, mt = 8): persistent workgroups walk the M tiles.
 extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, int mt, void* stream) {
   const int pt = p->patch_rows_max;
-  if ((mt != 7 && mt != 8) || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || (mt == 7 && grid_blocks != p->total_tiles) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 5 ||
+  if (mt < 4 || mt > 8 || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || (mt < 8 && grid_blocks != p->total_tiles) ||
+      (mt < 7 && (pt != 4 || nbd != 5)) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 5 ||
       (pt != 4 && pt != 5 && pt != 6) || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)) ||
       grid_blocks < p->ntiles || grid_blocks > p->total_tiles || grid_blocks % p->ntiles || (p->res && grid_blocks != p->total_tiles) ||
       p->total_tiles != p->mtiles * p->ntiles)
@@ -643,6 +664,12 @@ extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid
       default: w4_go_n<T, 5>(*p, pt, grid_blocks, mt, lds, st); break;                                         \
     }                                                                                                          \
   } while (0)
+  if (mt < 7) {
+#define GS(T) do { if (mt == 4) w4_go_small<T, 4>(*p, grid_blocks, lds, st); else if (mt == 5) w4_go_small<T, 5>(*p, grid_blocks, lds, st); else w4_go_small<T, 6>(*p, grid_blocks, lds, st); } while (0)
+    if (dtype == 0) GS(bf16_t); else GS(f16_t);
+#undef GS
+    return (int)hipGetLastError();
+  }
   if (dtype == 0) GO(bf16_t); else GO(f16_t);
 #undef GO
   return (int)hipGetLastError();

@@ -71,7 +71,7 @@ struct Conv {
   void* w_packed = nullptr;    // MFMA image (16-bit)
   void* w_stag = nullptr;      // conv_stag image (16-bit), 3x3 s1 Cout >= 128 only
   int stag = 0, stag_patch_bytes = 0, nseg = 1; size_t stag_lds = 0;
-  int w4_patch_224 = 0;                // conv_w4 on 224-pixel tiles: patch rounds of such a tile (0: not available)
+  int w4_patch[9] = {0};               // conv_w4 on 32 mt-pixel tiles, mt = 4..7: patch rounds of such a tile (0: not available)
   float* w_naive = nullptr;    // [ky][kx][ci][cout]
   float* bias = nullptr;
   // folded shortcut (conv_stag DSF): on a 1x1 downsample conv, folded = 1 means "computed inside layerX.0.conv2";
@@ -100,7 +100,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_head_fuse = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_head_fuse = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -223,11 +223,12 @@ void plan_conv(flope_engine* e, Conv& c) {
     if (P == 7) P = 8;                                 // (every round is 8 KB of L2 -> LDS traffic per half-chunk and tile)
     const size_t lds = (size_t)6 * sbn * 64 + (size_t)2 * P * 8192;   // 3 double tiles + 2 patch buffers
     if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }
-    if (c.cout >= 128) {                                // the 4-wave kernel's 224-pixel tiles (conv_w4.hip, MT = 7)
-      const long pc7 = (long)patch_rows(c, B, 224, false) * (Wip + 2) * 4;
-      const int P7 = std::max(4, (int)((pc7 + 511) / 512));
-      c.w4_patch_224 = P7 <= 6 ? P7 : 0;
-    }
+    if (c.cout >= 128)                                  // the 4-wave kernel's smaller tiles (conv_w4.hip, MT = 4..7)
+      for (int mt = 4; mt <= 7; ++mt) {
+        const long pcs = (long)patch_rows(c, B, 32 * mt, false) * (Wip + 2) * 4;
+        const int Pm = std::max(4, (int)((pcs + 511) / 512));
+        c.w4_patch[mt] = (mt == 7 ? Pm <= 6 : Pm == 4) ? Pm : 0;      // below 7: the 4-round instantiations only
+      }
     // layer-1 shape: 8-row bands of one image per tile (constant tile geometry, 7 bands per 56-row image)
     c.nseg = 1;
     if (c.cout == 64 && e->opt_stag >= 3 && c.hout % 8 == 0 && c.wout <= 64) {
@@ -521,7 +522,8 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
-  else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value == 7 || value == 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 7 / 8 = 224 / 256 pixels
+  else if (!strcmp(name, "w4mtlo")) { prev = e->opt_w4mtlo; e->opt_w4mtlo = value <= 0 ? 0 : (value < 4 ? 4 : (value > 8 ? 8 : value)); return prev; }   // smallest tile height the per-launch choice may take (0: 7 with two slices in flight, 5 alone)
+  else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value >= 4 && value <= 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 4..8 = 128..256 pixels (where the shape has that instantiation)
   else if (!strcmp(name, "head_fuse")) { prev = e->opt_head_fuse; e->opt_head_fuse = value != 0; return prev; }   // avgpool + fc.0 in one launch (bit-identical to the two)
   else if (!strcmp(name, "fc2_k4")) { prev = e->opt_fc2_k4; e->opt_fc2_k4 = value != 0; return prev; }            // fc_rot: K split over the four waves of a workgroup per image
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
@@ -760,15 +762,30 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
           if (gw < p.ntiles) gw = p.ntiles;
         }
         const int dsf = (p.ds_in && gw < p.total_tiles) ? 1 : 0;       // a folded shortcut needs its own weight slot only there
-        // 224- or 256-pixel tiles (one tile per workgroup): the cheaper of the two by whole rounds of the chip x the time of a
-        // tile (fixed ~15 k cycles of prologue + epilogue, ~1.5 k per double step of a 256-pixel tile, 7/8 of that + 5 % at 224)
+        // workgroup tiles of 256 .. 128 pixels (8 .. 4 pixel tiles per wave; one tile per workgroup): the cheapest by whole rounds
+        // of the chip x the time of a tile -- ~15 k cycles of prologue + epilogue, and per double step 128 cycles of MFMAs per
+        // pixel tile + ~500 of everything else (r03 stamps: 1.52 k at 8, 1.4 k at 7); ties go to the larger tile
         int mt = 8, ptr = c.stag_patch_bytes;
-        if (gw == p.total_tiles && c.w4_patch_224 && e->opt_w4mt != 8) {
-          const int t7 = (p.M + 223) / 224 * p.ntiles;
-          const double loop = 1500.0 * 9.0 * (c.cin / 64 + (p.ds_in ? 1 : 0));
-          const double c8 = (double)((p.total_tiles + e->num_cus - 1) / e->num_cus) * (15000.0 + loop);
-          const double c7 = (double)((t7 + e->num_cus - 1) / e->num_cus) * (15000.0 + loop * 0.875 * 1.05);
-          if (e->opt_w4mt == 7 || c7 < c8) { mt = 7; ptr = c.w4_patch_224; p.mtiles = (p.M + 223) / 224; p.total_tiles = p.mtiles * p.ntiles; gw = p.total_tiles; p.patch_rows_max = ptr; }
+        if (gw == p.total_tiles && e->opt_w4mt != 8) {
+          const double dsteps = 9.0 * (c.cin / 64 + (p.ds_in ? 1 : 0));
+          // Measured (profiles/r03_conv_w4_tile_height_ab.txt): with two batch slices in flight only 224 against 256 pays (+1.8 % on
+          // the step; letting the choice go down to 128 or sizing it to the slice's share of the CUs loses 2 - 5 %: the other slice's
+          // launches fill what a coarse tiling leaves idle).  A launch that has the chip to itself (one slice: batches below 64, the
+          // profile pass) gains another ~12 % from 192 / 160-pixel tiles where they save a round.
+          const int cus = e->num_cus;
+          const int mt_lo = e->opt_w4mtlo ? e->opt_w4mtlo : (e->cur_slices == 1 ? 5 : 7);
+          auto cost = [&](int m) {
+            const int t = (p.M + 32 * m - 1) / (32 * m) * p.ntiles;
+            return (double)((t + cus - 1) / cus) * (15000.0 + dsteps * (128.0 * m + 500.0));
+          };
+          double best = e->opt_w4mt ? 1e30 : cost(8);
+          for (int m = 7; m >= mt_lo; --m) {
+            if (!c.w4_patch[m] || (e->opt_w4mt && e->opt_w4mt != m)) continue;
+            if (m < 7 && (std::min(e->opt_w4, 5) != 5 || flope_conv_w4_lds(4, 5, 0) > kLdsMax)) continue;
+            const double cm = cost(m);
+            if (cm < best) { best = cm; mt = m; }
+          }
+          if (mt != 8) { ptr = c.w4_patch[mt]; p.mtiles = (p.M + 32 * mt - 1) / (32 * mt); p.total_tiles = p.mtiles * p.ntiles; gw = p.total_tiles; p.patch_rows_max = ptr; }
         }
         int nbd = std::min(e->opt_w4, 5);                  // weight-ring depth asked for; the deepest that fits the CU's LDS
         while (nbd > 3 && flope_conv_w4_lds(ptr, nbd, dsf) > kLdsMax) --nbd;
@@ -778,7 +795,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
           K_TRY(e, c.name.c_str(), flope_conv_w4_launch(&p, dt, nbd, gw, mt, stream));
           continue;
         }
-        if (mt == 7) { p.mtiles = (p.M + 255) / 256; p.total_tiles = p.mtiles * p.ntiles; p.patch_rows_max = c.stag_patch_bytes; }
+        if (mt != 8) { p.mtiles = (p.M + 255) / 256; p.total_tiles = p.mtiles * p.ntiles; p.patch_rows_max = c.stag_patch_bytes; }
       }
       size_t lds_bytes = c.stag_lds;
       if ((e->opt_dbg & 128) && lds_bytes + 2048 <= kLdsMax) { p.dbg_lds_off = (int)lds_bytes; lds_bytes += 2048; }

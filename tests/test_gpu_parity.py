@@ -113,8 +113,8 @@ def test_conflict_free_patch_image_and_4_wave_kernel_do_not_change_a_bit(state_d
     outs = []
     # w4: the 4-wave kernel (weight ring of <= 3..5 double tiles) or conv_stag; w4p: persistent workgroups for the convs without residual
     # (w4grid: a grid of 8 / 12 workgroups, so that each walks several tiles, the ragged last one included)
-    # w4mt: 224-pixel (7) or 256-pixel (8) workgroup tiles of the 4-wave kernel, 0 = chosen per launch
-    for skew, w4, w4p, grid, mt in ((1, 5, 1, 8, 8), (1, 5, 0, 0, 7), (1, 5, 0, 0, 8), (1, 4, 0, 0, 7), (1, 3, 0, 0, 7), (1, 5, 0, 0, 0), (1, 4, 1, 12, 8),
+    # w4mt: 256 .. 128-pixel (8 .. 4 pixel tiles per wave) workgroup tiles of the 4-wave kernel, 0 = chosen per launch
+    for skew, w4, w4p, grid, mt in ((1, 5, 1, 8, 8), (1, 5, 0, 0, 7), (1, 5, 0, 0, 8), (1, 4, 0, 0, 7), (1, 3, 0, 0, 7), (1, 5, 0, 0, 0), (1, 5, 0, 0, 6), (1, 5, 0, 0, 5), (1, 5, 0, 0, 4), (1, 4, 1, 12, 8),
                                     (1, 3, 1, 8, 8), (1, 5, 1, 0, 8), (1, 0, 0, 0, 0), (0, 0, 0, 0, 0)):
         e = _engine(state_dict, H, W, B, dtype, skew=skew, w4=w4, w4p=w4p, w4grid=grid, w4mt=mt)
         r9, R = _run(e, x)
