@@ -123,11 +123,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   const int cb = ntile * 128 + wch * 64 + g * 8;
   const float* const bias_p = p.bias + cb;
 
-#ifdef FLOPE_W4_OLDWAIT
-#define W4_WAIT_PIN() do {} while (0)
-#else
 #define W4_WAIT_PIN() __builtin_amdgcn_sched_barrier(0)
-#endif
 #define W4_WAIT_VM(n_)                                                                                         \
   do {                                                                                                         \
     W4_WAIT_PIN();                                         /* behind the sub-step's last MFMAs, not in front of them */ \
@@ -314,11 +310,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // them).  Program order IS the wanted order (the compiler keeps LDS-DMA and ds_read in program order: both touch LDS);
   // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.
 #define W4_NODMA(i_) do {} while (0)
-#ifdef FLOPE_W4_LATE_DMA        // the sub-step's DMA pieces in its LAST MFMA groups (groups 6, 7 carry no fragment reads)
-#define W4_G0(NV_, KV_) (MT - ((NV_) + (KV_) - 1) / ((KV_) > 0 ? (KV_) : 1))
-#else
-#define W4_G0(NV_, KV_) 0
-#endif
+#define W4_G0(NV_, KV_) 0        /* first MFMA group that carries DMA pieces (placing them in the LAST groups measured -0.5 %) */
 #ifndef FLOPE_W4_ASM_DMA
 #define W4_VMEM_GROUP(P_, NV_, KV_)                                                                            \
   do {                                                                                                         \
