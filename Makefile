@@ -37,4 +37,20 @@ dbg: $(DBGOBJS)
 clean:
 	rm -rf build $(LIB) $(HARNESS)
 
-.PHONY: all clean dbg
+# stand-alone measurement programs used by tools/collect_profiles.sh and DESIGN.md section 9 (not part of the library)
+TOOLBINS := build/fetch_calib build/launch_floor build/loop_probe build/dma_issue_probe
+build/fetch_calib: tools/calib/fetch_calib.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+build/launch_floor: tools/calib/launch_floor.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+build/loop_probe: tools/probes/loop_probe.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+build/dma_issue_probe: tools/probes/dma_issue_probe.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+tools: $(TOOLBINS)
+
+.PHONY: all clean dbg tools
