@@ -60,12 +60,14 @@ def enqueue_poses(posenet, frame_shape, boxes, K, depth_div, frame_d, mask_d, de
     if good_bb.shape[0] == 0:
         return None
     K4 = (K[0][0], K[1][1], K[0][2], K[1][2])
-    _, reliable, xyz = _engine.depth_lift(depth_d, mask_d, torch.from_numpy(good_bb.astype(np.int32)), K4,
-                                          depth_div, near, far)
+    # both box lists in ONE host -> device copy (each small pageable copy is a synchronous ~30 us call)
+    n_box = good_bb.shape[0]
+    both = torch.from_numpy(np.concatenate([good_bb.astype(np.int32), sq_bb.astype(np.int32)], axis=0)).to(dev)
+    _, reliable, xyz = _engine.depth_lift(depth_d, mask_d, both[:n_box], K4, depth_div, near, far)
     # Every in-frame box goes through the network and the unreliable ones are dropped at the very end: one device ->
     # host round trip per frame instead of two (the reference filters first; crops are independent, so the surviving rows are
     # the same poses up to fp32 summation order).
-    sq_all = torch.from_numpy(sq_bb.astype(np.int32)).to(dev)
+    sq_all = both[n_box:]
     # crops in the trunk's own 16-bit NHWC layout when there is one: the stem would round the float32 crop to that type
     # anyway (bit-identical result), and the crop tensor is a third of the size
     fmt = {"f16": _lib.IN_F16_NHWC, "bf16": _lib.IN_BF16_NHWC}.get(getattr(posenet, "compute_dtype", "f32"), _lib.IN_F32_NCHW)
