@@ -16,11 +16,13 @@
 //     double tile (counted vmcnt), then the barrier publishes them; the reads of the following sub-step come after it.
 // Same LDS images (conflict-free patch image of conv_stag r03, weight ring of double tiles), same packed weights, same
 // register epilogue (lane = one pixel x 16 channels in two runs of 8), same folded 1x1 stride-2 shortcut, residual by
-// LDS-DMA in the slots the look-ahead of the last body leaves unused.  One tile per workgroup; split-K and persistent grids
-// stay on conv_stag.
+// LDS-DMA in the slots the look-ahead of the last body leaves unused.  One tile per workgroup (a persistent tile walk exists as the
+// measured-slower option PERS); split-K stays on conv_stag.  The tile HEIGHT is a template argument (MT = 8..4 pixel
+// tiles of 16 per wave = 256..128-pixel workgroup tiles): the engine picks it per launch by whole rounds of the chip (DESIGN.md
+// 9.7b) -- every height runs the same MFMA sequence per output, so all of them are bit-identical.
 #include "common.h"
 
-// LDS-DMA as inline assembly, hidden from hipcc's wait-count pass.  While that pass knows of one outstanding flat-encoded access that
+// LDS-DMA, optionally (FLOPE_W4_ASM_DMA) as inline assembly hidden from hipcc's wait-count pass.  While that pass knows of one outstanding flat-encoded access that
 // may land in LDS (its "pending flat" state; global_load_lds counts as one) it forces every wait it inserts to 0: lgkmcnt(0) in
 // front of each sub-step's first MFMA (instead of counting the younger fragment reads it may leave in flight) and vmcnt(0) at the
 // first use of any ordinary load.  This kernel counts its DMAs itself (W4_WAIT_VM); the "memory" clobber keeps every ds_read /
@@ -45,8 +47,8 @@ __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 1
 // (r03: loading the table from memory instead -- precomputed per tile geometry class, 49 classes x 20 KiB per conv, 20 coalesced
 // 16-byte loads per lane -- was measured and dropped: the loads took 10-12 k cycles against 5 k for computing it, the tables do not
 // stay in L2 between tiles; step 1.116 vs 1.094 ms in same-run A/B.)
-// PT: 8 KB DMA rounds per patch buffer (4, 5 or 6).  NBD: double tiles in the weight ring (3 or 4; the DMA runs NBD - 1
-// double steps ahead of its consumer).  RES: residual input.  DSF: folded 1x1 stride-2 shortcut (no residual).
+// PT: 8 KB DMA rounds per patch buffer (4, 5 or 6).  NBD: double tiles in the weight ring (3, 4 or 5; the DMA runs NBD - 1
+// double steps ahead of its consumer).  MT: pixel tiles per wave (8..4; below 7 only PT = 4, NBD = 5 are instantiated).  RES: residual input.  DSF: folded 1x1 stride-2 shortcut (no residual).
 // PERS (no residual input): at most one workgroup per CU walks M tiles mt, mt + G, ... of its channel tile.  The step stream does
 // not stop at a tile boundary: the weight ring wraps to the start of the panel (= the next tile's first double tiles) and the
 // patch burst of double step 5 of a tile's last body fetches the NEXT tile's first half-chunk -- r03 stamps: of the 9-10 k cycles a
