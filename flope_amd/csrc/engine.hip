@@ -43,6 +43,9 @@ extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_stem_pool_init();
+#ifdef FLOPE_STAG_DBG
+extern "C" void flope_stem_pool_set_dbg(void* ptr);
+#endif
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
                                       const void* w, const float* bias, void* out, int dtype, int persist_blocks, int regpool, void* stream);
 
@@ -648,6 +651,9 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
   const bool fused = e->opt_fuse_stem && dt != FLOPE_DT_F32;
   if (fused) {
     SMARK();
+#ifdef FLOPE_STAG_DBG
+    flope_stem_pool_set_dbg(((e->opt_dbg & 64) && e->split_ws) ? (void*)(e->split_ws + (size_t)30 * (kDbgRegion / 4)) : nullptr);
+#endif
     K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w,
                                                    e->stem_bias, bp.ptr, dt,
                                                    // persistent form where it measured faster (r02, same-run A/B at B = 256): 224 x 224 crops

@@ -28,6 +28,9 @@ struct StemPoolP {
   int Hs, Ws;          // conv output size
   int Hq, Wq;          // pooled output size
   int tiles_y, tiles_x;
+#ifdef FLOPE_STAG_DBG
+  unsigned long long* dbg;   // diagnostic build: per workgroup {cycles in 5 phases, tiles, total} (tools/clock_probe_stem.py)
+#endif
 };
 
 template <typename T> __device__ __forceinline__ u32x2 pack4(float a, float b, float c) {
@@ -361,6 +364,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
   if (tile < total) { issue_loads(tile); write_window(); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef FLOPE_STAG_DBG
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_first = t_prev;
+  int ntile_dbg = 0;
+#define ST_PH(i_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i_] += t_ - t_prev; t_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ST_PH(i_) do {} while (0)
+#endif
 
   for (; tile < total; tile += G) {
     int tx, ty, img;
@@ -386,7 +396,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], acc[pt][ct]);
     }
+    ST_PH(0);
     __syncthreads();                               // Ps is free (and the previous tile's pool has finished with Cs)
+    ST_PH(1);
     if (has_next) write_window();
     {
       const bool edge = cr0 < 0 || cc0 < 0 || cr0 + CR > p.Hs || cc0 + CR > p.Ws;
@@ -412,7 +424,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
         }
       }
     }
+    ST_PH(2);
     __syncthreads();
+    ST_PH(3);
     for (int i = tid; i < 64 * 8; i += 256) {
       const int cg = i & 7, pp = i >> 3;
       const int pr = pp >> 3, pc = pp & 7;
@@ -431,7 +445,19 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
       char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
       *(u32x4*)dst = o;
     }
+    ST_PH(4);
+#ifdef FLOPE_STAG_DBG
+    ++ntile_dbg;
+#endif
   }
+#ifdef FLOPE_STAG_DBG
+  if (p.dbg && tid == 0) {
+    unsigned long long* d_ = p.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; ++i) d_[i] = ph[i];
+    d_[5] = (unsigned long long)ntile_dbg; d_[6] = __builtin_amdgcn_s_memtime() - t_first;
+  }
+#endif
+#undef ST_PH
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -642,10 +668,18 @@ extern "C" int flope_stem_pool_init() {
 
 // persist_blocks > 0: a persistent kernel on that many workgroups; 0: one workgroup per tile.
 // regpool != 0 (with persist_blocks > 0): the register-pool kernel (7 x 7 pooled pixels per tile, three workgroups per CU)
+#ifdef FLOPE_STAG_DBG
+static unsigned long long* g_stem_dbg = nullptr;
+extern "C" void flope_stem_pool_set_dbg(void* ptr) { g_stem_dbg = (unsigned long long*)ptr; }
+#endif
+
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq,
                                       int Wq, const void* w, const float* bias, void* out, int dtype, int persist_blocks,
                                       int regpool, void* stream) {
   StemPoolP p;
+#ifdef FLOPE_STAG_DBG
+  p.dbg = g_stem_dbg;
+#endif
   p.x = x; p.out = out; p.w = w; p.bias = bias; p.in_format = in_format;
   p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws_; p.Hq = Hq; p.Wq = Wq;
   p.tiles_y = (Hq + 7) / 8; p.tiles_x = (Wq + 7) / 8;

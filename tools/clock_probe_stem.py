@@ -1,0 +1,42 @@
+"""Persistent stem kernel, diagnostic build: cycles per tile and workgroup in each phase.
+    make dbg && FLOPE_AMD_LIB=build/dbg/libflope_amd_dbg.so python tools/clock_probe_stem.py [streams]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flope_amd.engine import PoseEngine  # noqa: E402
+from flope_amd.weights import synthetic_state_dict  # noqa: E402
+
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+B, S = int(os.environ.get("B", 256)), int(os.environ.get("S", 224))
+x = torch.rand(B, S, S, 3).to(torch.float16).cuda()
+R = torch.empty(B, 9, device="cuda")
+e = PoseEngine(S, S, B, "f16")
+e.set_option("streams", streams)
+e.load_state_dict(synthetic_state_dict(0))
+e.set_option("dbg", 64)
+t0 = time.time()
+while time.time() - t0 < 2.0:
+    for _ in range(20):
+        e.forward_into(x, 2, None, R)
+    torch.cuda.synchronize()
+buf = np.zeros(1024 * 8, dtype=np.uint64)
+rc = e.lib.flope_debug_read_ws(e.handle, buf.ctypes.data_as(C.c_void_p), C.c_size_t(30 * 1048576), C.c_size_t(buf.nbytes))
+assert rc == 0
+r = buf.reshape(-1, 8).astype(np.int64)
+r = r[(r[:, 5] > 0) & (r[:, 6] > 0) & (r[:, 6] < 10**9)]
+tiles = r[:, 5]
+names = ["loads issue + acc init + MFMA phase", "barrier 1", "window write + ReLU -> Cs", "barrier 2", "pool + store"]
+print(f"B={B} S={S} streams={streams}: {len(r)} workgroups, {int(tiles.sum())} tiles; cycles per tile and workgroup (median over workgroups)")
+tot = 0
+for i, n in enumerate(names):
+    v = np.median(r[:, i] / tiles)
+    tot += v
+    print(f"  {n:40s} {v:8.0f}")
+print(f"  {'sum':40s} {tot:8.0f}   (MFMA floor per tile and wave: 140 MFMAs x 16 = 2240)")
