@@ -12,6 +12,7 @@
 // LDS (aliasing the weight/input staging), max-pools there and writes 16-byte NHWC vectors.
 // The one-pixel conv halo is recomputed by the neighbour tile (289 conv px per 256 consumed).
 #include "common.h"
+#include "host_pack.h"
 #include <type_traits>
 
 #define GLDS16(gptr, lptr)                                                                         \
@@ -28,6 +29,7 @@ struct StemPoolP {
   int Hs, Ws;          // conv output size
   int Hq, Wq;          // pooled output size
   int tiles_y, tiles_x;
+  unsigned mg_tx, sh_tx, mg_ty, sh_ty;   // n / tiles_x and n / tiles_y as multiply-shift (host_pack.h fastdiv_magic)
 #ifdef FLOPE_STAG_DBG
   unsigned long long* dbg;   // diagnostic build: per workgroup {cycles in 5 phases, tiles, total} (tools/clock_probe_stem.py)
 #endif
@@ -278,9 +280,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
   // short c2; u8: one short c0|c1 and one byte c2) -- any unpacking here would have to wait for the loads, before the MFMAs
   unsigned raw[NI][3];
   unsigned okmask = 0;
-  auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {
-    tx = tile % p.tiles_x; const int q = tile / p.tiles_x;
-    ty = q % p.tiles_y; img = q / p.tiles_y;
+  auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {     // (multiply-shift: two runtime divisions were ~80 instructions per tile)
+    const int q = fastdiv(tile, p.mg_tx, p.sh_tx);
+    tx = tile - q * p.tiles_x;
+    img = fastdiv(q, p.mg_ty, p.sh_ty);
+    ty = q - img * p.tiles_y;
   };
   auto issue_loads = [&](int tile) {
     int tx, ty, img;
@@ -360,6 +364,25 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) b4[ct] = *(const f32x4*)(p.bias + g * 16 + ct * 4);
 
+  // tile-independent LDS offsets (r03: the stamps say a wave's own instruction stream, not a shared unit, bounds this kernel):
+  // where this lane parks its conv outputs, and the nine conv outputs under each of its two pool items
+  int cso[MT][2];
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) {
+    const int q = qidx[pt] < 0 ? 0 : qidx[pt];
+    cso[pt][0] = q * 128 + (((2 * g) ^ (q & 7)) << 4);
+    cso[pt][1] = q * 128 + (((2 * g + 1) ^ (q & 7)) << 4);
+  }
+  int pro[2][9];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = tid + it * 256, cg = i & 7, pp = i >> 3, pr = pp >> 3, pc = pp & 7;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int q = (2 * pr + t / 3) * CR + 2 * pc + t % 3;
+      pro[it][t] = q * 128 + ((cg ^ (q & 7)) << 4);
+    }
+  }
   int tile = lb;
   if (tile < total) { issue_loads(tile); write_window(); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -367,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #ifdef FLOPE_STAG_DBG
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_first = t_prev;
   int ntile_dbg = 0;
+  unsigned long long ph_pre = 0;                   // part of phase 0 in front of the MFMA loop (tile decode + window loads issue)
 #define ST_PH(i_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i_] += t_ - t_prev; t_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ST_PH(i_) do {} while (0)
@@ -379,11 +403,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
     const bool has_next = tile + G < total;
     if (has_next) issue_loads(tile + G);           // in flight during the MFMA phase
     asm volatile("" ::: "memory");
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int pt = 0; pt < MT; ++pt)
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
+#ifdef FLOPE_STAG_DBG
+    { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_pre += t_ - t_prev; __builtin_amdgcn_sched_barrier(0); }
+#endif
+    f32x4 acc[MT][NT];                               // row 0 takes the folded-BN bias as its C operand: no 80-register init
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       frag wf[NT], xf[MT];
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #pragma unroll
       for (int pt = 0; pt < MT; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], acc[pt][ct]);
+        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], ky == 0 ? b4[ct] : acc[pt][ct]);
     }
     ST_PH(0);
     __syncthreads();                               // Ps is free (and the previous tile's pool has finished with Cs)
@@ -419,29 +442,28 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
             const int cr = cr0 + qr, cc = cc0 + qc;
             if (!(cr >= 0 && cr < p.Hs && cc >= 0 && cc < p.Ws)) { o[0] = u32x4{0u, 0u, 0u, 0u}; o[1] = o[0]; }
           }
-          *(u32x4*)(Cs + q * 128 + (((2 * g) ^ (q & 7)) << 4)) = o[0];
-          *(u32x4*)(Cs + q * 128 + (((2 * g + 1) ^ (q & 7)) << 4)) = o[1];
+          *(u32x4*)(Cs + cso[pt][0]) = o[0];
+          *(u32x4*)(Cs + cso[pt][1]) = o[1];
         }
       }
     }
     ST_PH(2);
     __syncthreads();
     ST_PH(3);
-    for (int i = tid; i < 64 * 8; i += 256) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + it * 256;
       const int cg = i & 7, pp = i >> 3;
       const int pr = pp >> 3, pc = pp & 7;
       const int oy = ty * 8 + pr, ox = tx * 8 + pc;
       if (oy >= p.Hq || ox >= p.Wq) continue;
       u32x4 o = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+      for (int t = 0; t < 9; ++t) {
+        const u32x4 v = *(const u32x4*)(Cs + pro[it][t]);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int q = (2 * pr + dy) * CR + 2 * pc + dx;
-          const u32x4 v = *(const u32x4*)(Cs + q * 128 + ((cg ^ (q & 7)) << 4));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
-        }
+        for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
+      }
       char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
       *(u32x4*)dst = o;
     }
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
   if (p.dbg && tid == 0) {
     unsigned long long* d_ = p.dbg + (size_t)blockIdx.x * 8;
     for (int i = 0; i < 5; ++i) d_[i] = ph[i];
-    d_[5] = (unsigned long long)ntile_dbg; d_[6] = __builtin_amdgcn_s_memtime() - t_first;
+    d_[5] = (unsigned long long)ntile_dbg; d_[6] = __builtin_amdgcn_s_memtime() - t_first; d_[7] = ph_pre;
   }
 #endif
 #undef ST_PH
@@ -683,6 +705,8 @@ extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H
   p.x = x; p.out = out; p.w = w; p.bias = bias; p.in_format = in_format;
   p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws_; p.Hq = Hq; p.Wq = Wq;
   p.tiles_y = (Hq + 7) / 8; p.tiles_x = (Wq + 7) / 8;
+  flope_host::fastdiv_magic((unsigned)p.tiles_x, &p.mg_tx, &p.sh_tx);
+  flope_host::fastdiv_magic((unsigned)p.tiles_y, &p.mg_ty, &p.sh_ty);
   const dim3 block(256);
   if (persist_blocks > 0 && regpool) {
     p.tiles_y = (Hq + 6) / 7; p.tiles_x = (Wq + 6) / 7;

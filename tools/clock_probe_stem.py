@@ -39,4 +39,5 @@ for i, n in enumerate(names):
     v = np.median(r[:, i] / tiles)
     tot += v
     print(f"  {n:40s} {v:8.0f}")
+print(f"  {'(of phase 0: tile decode + loads issue)':40s} {np.median(r[:, 7] / tiles):8.0f}")
 print(f"  {'sum':40s} {tot:8.0f}   (MFMA floor per tile and wave: 140 MFMAs x 16 = 2240)")
