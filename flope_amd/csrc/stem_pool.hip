@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemPoolP p) {
 #pragma unroll
           for (int w2 = 0; w2 < 4; ++w2) {
             const int c = h * 8 + w2 * 2;                   // channel pair c, c+1 of this lane's 16
-            o[h][w2] = pk_out16<T>(pack2<T>(acc[pt][c >> 2][c & 3], acc[pt][(c + 1) >> 2][(c + 1) & 3]), true);
+            o[h][w2] = pk_relu16<T>(pack2<T>(acc[pt][c >> 2][c & 3], acc[pt][(c + 1) >> 2][(c + 1) & 3]));
           }
         if (edge) {
           const int qr = q / CR, qc = q - qr * CR;
@@ -280,6 +280,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
   // short c2; u8: one short c0|c1 and one byte c2) -- any unpacking here would have to wait for the loads, before the MFMAs
   unsigned raw[NI][3];
   unsigned okmask = 0;
+  unsigned rowmask = 0;                              // rows r0 + 6k that exist in the 39-row window
+#pragma unroll
+  for (int k = 0; k < NI; ++k) if (r0 + 6 * k < PR) rowmask |= 1u << k;
   auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {     // (multiply-shift: two runtime divisions were ~80 instructions per tile)
     const int q = fastdiv(tile, p.mg_tx, p.sh_tx);
     tx = tile - q * p.tiles_x;
@@ -291,15 +294,26 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
     tile_origin(tile, tx, ty, img);
     const int py0 = 2 * (2 * (ty * 8) - 1) - 3, px0 = 2 * (2 * (tx * 8) - 1) - 3;
     const int x = px0 + c;
-    const bool okx = x >= 0 && x < p.W;
-    const int xoffs = min(max(x, 0), p.W - 1) * estep;
-    okmask = 0;
     int off[NI];
+    // a window that lies inside the image (wave-uniform test; about half of the tiles of a 224 x 224 crop) needs neither the
+    // clamps nor the per-row masks: one multiply, six adds
+    if (py0 >= 0 && py0 + PR <= p.H && px0 >= 0 && px0 + PC <= p.W) {
+      okmask = rowmask;
+      const int rs = 6 * p.W * estep;
+      off[0] = ((py0 + r0) * p.W + x) * estep;
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int r = r0 + 6 * k, y = py0 + r;
-      if (okx && r < PR && y >= 0 && y < p.H) okmask |= 1u << k;
-      off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;
+      for (int k = 1; k < NI; ++k) off[k] = off[k - 1] + rs;
+      if (r0 + 6 * (NI - 1) >= PR) off[NI - 1] = off[NI - 2];     // the row behind the window: any legal address
+    } else {
+      const bool okx = x >= 0 && x < p.W;
+      const int xoffs = min(max(x, 0), p.W - 1) * estep;
+      okmask = 0;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int r = r0 + 6 * k, y = py0 + r;
+        if (okx && r < PR && y >= 0 && y < p.H) okmask |= 1u << k;
+        off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;
+      }
     }
     if constexpr (FMT == 0) {
       const float* s = (const float*)p.x + (size_t)img * img_elems;
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) {
               const int ch = h * 8 + w2 * 2;
-              o[h][w2] = pk_out16<T>(pack2<T>(acc[pt][ch >> 2][ch & 3], acc[pt][(ch + 1) >> 2][(ch + 1) & 3]), true);
+              o[h][w2] = pk_relu16<T>(pack2<T>(acc[pt][ch >> 2][ch & 3], acc[pt][(ch + 1) >> 2][(ch + 1) & 3]));
             }
           if (edge) {
             const int qr = q / CR, qc = q - qr * CR;
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_regpool_kernel(const StemPoo
 #pragma unroll
           for (int w2 = 0; w2 < 4; ++w2) {
             const int ch = h * 8 + w2 * 2;
-            const unsigned v = pk_out16<T>(pack2<T>(acc[pt][ch >> 2][ch & 3], acc[pt][(ch + 1) >> 2][(ch + 1) & 3]), true);
+            const unsigned v = pk_relu16<T>(pack2<T>(acc[pt][ch >> 2][ch & 3], acc[pt][(ch + 1) >> 2][(ch + 1) & 3]));
             o[pt][h][w2] = ok ? v : 0u;
           }
       }
