@@ -81,6 +81,8 @@ template <> __device__ __forceinline__ unsigned pk_out16<f16_t>(unsigned w, bool
   const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), z));
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(h2_t, x), hi), lo));
 }
+// (r03: the same clamp as integer mins -- three instructions per pair instead of five -- changed no conv's time: the conv epilogues
+// are store-bound; the stem, which is bound by its instruction stream, uses pk_relu16 below)
 
 // ReLU known at compile time (stem): after the integer max the value is a non-negative 16-bit float pattern, and those order like
 // integers, so the clamp to 65504 (+inf and NaN patterns 0x7C00..0x7FFF included: pk_out16's float min returns the number for a NaN)
