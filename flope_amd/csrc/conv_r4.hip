@@ -12,12 +12,12 @@
 //   * the 72 KB weight panel is resident in LDS; the two patch buffers (one per 32-channel half-chunk, 10 input rows each, the
 //     conflict-free image of conv_stag r03: row pitch W + 4) are refilled NINE sub-steps before their first reader:
 //       sub-step 0  : issue this tile's second half-chunk            -> buffer 1   (free since the previous tile's sub-step 17)
-//       before 8    : wait vmcnt(0), barrier                          (buffer 1 visible; every wave is done with buffer 0)
+//       before 8    : wait vmcnt(0) [RES: vmcnt(2 MT)], barrier       (buffer 1 visible; every wave is done with buffer 0)
 //       sub-step 8  : issue the NEXT tile's first half-chunk          -> buffer 0
 //       before 17   : wait vmcnt(0), barrier                          (buffer 0 visible; every wave is done with buffer 1)
 //     -- two barriers per tile (504 MFMAs per wave), every DMA / store / residual load has >= 8 sub-steps (~2 us) to complete,
-//     and every wait is a plain vmcnt(0): nothing this wave still needs to stay in flight is outstanding at either point;
-//   * the residual of the NEXT tile is loaded into registers at the end of a tile's epilogue and added in the next epilogue.
+//     the waits are plain vmcnt(0) except that the residual loads (RES: 2 per pixel tile, issued in sub-steps 1..7 straight into
+//     registers, added in the epilogue) stay in flight across the first barrier;
 // Every tile has the same geometry relative to its patch origin: all per-lane tables are built once per workgroup.
 #include "common.h"
 
@@ -208,7 +208,11 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
     R4_SUB(1); R4_SUB(2); R4_SUB(3); R4_SUB(4); R4_SUB(5); R4_SUB(6); R4_SUB(7);
     R4_STAMP(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's fragments of sub-step 8 (the last reads of buffer 0) are in registers
-    R4_WAIT_VM0();                                           // its pieces of the second half-chunk (and the last tile's stores) are done
+    // its pieces of the second half-chunk (and the last tile's stores) are done.  RES (r03b): the 2 MT residual loads of sub-steps
+    // 1..7 are YOUNGER than that burst and are not needed before the epilogue -- they stay in flight (waiting for them here, with
+    // a plain vmcnt(0), was 2.7-3.0 k cycles of every residual tile: profiles/r03_conv_r4_residual_wait.txt); the vmcnt(0) in
+    // front of sub-step 17 still covers them
+    if constexpr (RES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MT) : "memory"); else R4_WAIT_VM0();
     R4_BARRIER();
     R4_STAMP(2);
     R4_SUB(8); R4_SUB(9); R4_SUB(10); R4_SUB(11); R4_SUB(12); R4_SUB(13); R4_SUB(14); R4_SUB(15); R4_SUB(16);
