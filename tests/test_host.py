@@ -333,3 +333,18 @@ def test_pose_predictor_without_front_end_names_what_is_missing(tmp_path, state_
     # injected callables need no reference modules
     p = PosePredictor("cpu", ckpt, intr, detector=lambda rgb: np.zeros((0,)), segmenter=lambda rgb, bb: None)
     assert p.get_flower_poses(np.zeros((480, 640, 3), np.uint8), np.zeros((480, 640), np.uint16)) is None   # :76-78
+
+
+def test_integer_relu_clamp_equals_the_float_form_for_every_float16_pattern():
+    """common.h pk_relu16<f16_t> (stem, r03): ReLU + saturation of a packed float16 pair as integer max(w, 0) then integer
+    min(., 0x7BFF).  Restated here on all 65,536 bit patterns against the float form it replaces (pk_out16<f16_t>(w, true):
+    integer max with 0, then fmin(x, 65504) -- which returns the number when x is a NaN -- then fmax(x, -65504))."""
+    import numpy as np
+    w = np.arange(65536, dtype=np.uint32).astype(np.uint16)
+    relu_i = np.maximum(w.view(np.int16), np.int16(0))                     # both forms start with the signed-integer max
+    got = np.minimum(relu_i, np.int16(0x7BFF)).view(np.uint16)
+    x = relu_i.view(np.float16).astype(np.float32)
+    x = np.where(np.isnan(x), np.float32(65504.0), np.minimum(x, np.float32(65504.0)))       # minnum semantics
+    x = np.maximum(x, np.float32(-65504.0))
+    ref = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, ref)
