@@ -522,7 +522,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   if (!strcmp(name, "patch")) { prev = e->opt_patch; e->opt_patch = value != 0; }
   else if (!strcmp(name, "bm256")) { prev = e->opt_bm256; e->opt_bm256 = value != 0; }
   else if (!strcmp(name, "persist")) { prev = e->opt_persist; e->opt_persist = value != 0; return prev; }
-  else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? 0 : value; return prev; }
+  else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? -1 : value; return prev; }   // layer-1 persistent grid: 0 = one workgroup per CU, -1 = the slice's share of the CUs, > 0 = that many
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
   else if (!strcmp(name, "w4mtlo")) { prev = e->opt_w4mtlo; e->opt_w4mtlo = value <= 0 ? 0 : (value < 4 ? 4 : (value > 8 ? 8 : value)); return prev; }   // smallest tile height the per-launch choice may take (0: 7 with two slices in flight, 5 alone)
@@ -719,9 +719,12 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       int gridb = (e->opt_persist && c.ds_conv < 0)
                       ? std::min(p.total_tiles, std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))))
                       : p.total_tiles;
-      if (c.stag == 2)    // this slice's share of the CUs (slices in flight together cover the chip once)
+      if (c.stag == 2)    // the whole chip.  (r02 sized this grid to the slice's share of the CUs, on the idea that the slices run
+        // layer 1 side by side.  The r03 kernel trace -- tools/step_timeline.py -- shows they do not: the second slice starts ~0.3 ms
+        // after the first, whose layer 1 then sat on 96 of 256 CUs; rows_grid = -1 restores the share, > 0 sets the grid.)
         gridb = std::min(p.total_tiles, e->opt_rows_grid > 0 ? e->opt_rows_grid
-                                          : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
+                                          : e->opt_rows_grid < 0 ? std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch)))
+                                                                 : e->num_cus);
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
       // r03: layer 1 (64 -> 64 on the 56-wide map) on the 4-wave row-band kernel (conv_r4.hip)
@@ -887,11 +890,12 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   // join every stream that was forked -- also after a failed launch, so that work already queued on the side
   // streams stays ordered before the caller's next use of x / r9 / R / Rt
   const std::string first_err = rc_all != FLOPE_OK ? e->err : std::string();
-  for (int s = 0; s < forked; ++s)
+  for (int s = 0; s < forked; ++s) {
     if (hipEventRecord(e->ev_join[s], e->side[s]) != hipSuccess || hipStreamWaitEvent(user, e->ev_join[s], 0) != hipSuccess) {
       hipStreamSynchronize(e->side[s]);
       if (rc_all == FLOPE_OK) rc_all = fail(e, FLOPE_EHIP, "joining the batch-slice streams failed");
     }
+  }
   if (rc_all != FLOPE_OK) {
     if (!first_err.empty()) { e->err = first_err; g_last_error = first_err; }
     e->cur_slices = 1; e->cur_batch = 1; e->last_batch = 0;
