@@ -719,9 +719,9 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       int gridb = (e->opt_persist && c.ds_conv < 0)
                       ? std::min(p.total_tiles, std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))))
                       : p.total_tiles;
-      if (c.stag == 2)    // the whole chip.  (r02 sized this grid to the slice's share of the CUs, on the idea that the slices run
-        // layer 1 side by side.  The r03 kernel trace -- tools/step_timeline.py -- shows they do not: the second slice starts ~0.3 ms
-        // after the first, whose layer 1 then sat on 96 of 256 CUs; rows_grid = -1 restores the share, > 0 sets the grid.)
+      if (c.stag == 2)    // one workgroup per CU.  (r02 sized this grid to the slice's share of the CUs; two whole-chip grids
+        // interleave more evenly: +0.7 .. +2.5 % on the two-slice step in un-profiled same-run pairs, DESIGN.md 9.7c.
+        // rows_grid = -1 restores the share, > 0 sets the grid.)
         gridb = std::min(p.total_tiles, e->opt_rows_grid > 0 ? e->opt_rows_grid
                                           : e->opt_rows_grid < 0 ? std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch)))
                                                                  : e->num_cus);

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_first = t_prev;
   int ntile_dbg = 0;
   unsigned long long ph_pre = 0;                   // part of phase 0 in front of the MFMA loop (tile decode + window loads issue)
+  if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[8192 + (p.B & 1023)] = __builtin_amdgcn_s_memrealtime();   // launch start, by batch size (100 MHz clock): when does each slice's first kernel start?
 #define ST_PH(i_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i_] += t_ - t_prev; t_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ST_PH(i_) do {} while (0)
