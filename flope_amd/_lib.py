@@ -28,6 +28,7 @@ SIGNATURES = {
     "flope_forward_poses": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "flope_extract_features": (_I, [_P, _P, _I, _I, _P, _P]),
     "flope_procrustes": (_I, [_P, _P, _I, _P]),
+    "flope_profile_timeline": (_I, [_P, _P, _P, _I]),
     "flope_nullify_yaw": (_I, [_P, _P, _I, _P]),
     "flope_compose_pose": (_I, [_P, _P, _I, _I, _P, _P]),
     "flope_crop_resize_mask": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, _P, _P]),

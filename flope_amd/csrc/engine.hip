@@ -109,6 +109,8 @@ struct flope_engine {
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;        // profile mode: one event before every launch + one after the last
   int ev_n = 0;
+  std::vector<int> ev_slice;         // profile = 2: the slice whose stream recorded event i
+  int mark_slice = 0;
   int last_batch = 0;
   bool last_fused = false;
   std::string err;
@@ -138,8 +140,10 @@ int fail(flope_engine* e, int code, const std::string& msg) {
 
 #define MARK(e, stream)                                                                    \
   do {                                                                                     \
-    if ((e)->opt_profile && (e)->ev_n < (int)(e)->ev.size())                               \
+    if ((e)->opt_profile && (e)->ev_n < (int)(e)->ev.size()) {                             \
+      (e)->ev_slice[(e)->ev_n] = (e)->mark_slice;                                          \
       HIP_TRY(e, hipEventRecord((e)->ev[(e)->ev_n++], (hipStream_t)(stream)));             \
+    }                                                                                      \
   } while (0)
 
 int out_dim(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
@@ -481,7 +485,8 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
   }
   CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-  e->ev.resize(e->convs.size() + 8);
+  e->ev.resize(4 * (e->convs.size() + 8) + 2);       // profile = 2: up to four slices' marks + the fork
+  e->ev_slice.assign(e->ev.size(), 0);
   for (hipEvent_t& ev : e->ev) CREATE_TRY(hipEventCreate(&ev));
   CREATE_TRY(hipDeviceSynchronize());
 #undef CREATE_TRY
@@ -548,7 +553,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "ldspad")) { prev = e->opt_ldspad; e->opt_ldspad = value; return prev; }
   else if (!strcmp(name, "dbg")) { prev = e->opt_dbg; e->opt_dbg = value; return prev; }
   else if (!strcmp(name, "nbuf")) { prev = e->opt_nbuf; e->opt_nbuf = value == 2 ? 2 : 3; }
-  else if (!strcmp(name, "profile")) { prev = e->opt_profile; e->opt_profile = value != 0; e->ev_n = 0; return prev; }
+  else if (!strcmp(name, "profile")) { prev = e->opt_profile; e->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value); e->ev_n = 0; return prev; }   // 1: one slice, an event around every launch (flope_profile_read); 2: the slices as in production, events on every slice's stream (flope_profile_timeline)
   else return fail(e, FLOPE_EINVAL, std::string("flope_set_option: unknown option ") + name);
   rebuild_plan(e);
   return prev;
@@ -860,12 +865,14 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   e->ev_n = 0;
   e->last_fused = e->opt_fuse_stem && e->dtype != FLOPE_DT_F32;
   e->last_batch = batch;
-  int ns = (e->opt_streams >= 2 && !e->opt_profile) ? e->opt_streams : 1;
+  int ns = (e->opt_streams >= 2 && e->opt_profile != 1) ? e->opt_streams : 1;
   while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
   e->cur_slices = ns;
   e->cur_batch = batch;
+  e->mark_slice = 0;
   if (ns == 1) return run_slice(e, x_dev, in_format, 0, batch, stream, true, head, r9_dev, R_dev, po);
   hipStream_t user = (hipStream_t)stream;
+  if (e->opt_profile == 2) MARK(e, user);             // time zero of flope_profile_timeline
   HIP_TRY(e, hipEventRecord(e->ev_fork, user));
   // slices are launched layer-interleaved?  No: each slice's whole sequence goes to its own stream; the
   // hardware queues interleave them, and a slice's short tail round overlaps another slice's next launch.
@@ -878,14 +885,16 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
     int start = bound(s), cnt = bound(s + 1) - start;
     if (ns == 2) {
       // Two slices of 3/8 and 5/8 of the batch (multiples of 8 images, so every layer's tiles stay whole) instead of
-      // two halves: equal halves run the same layer at the same time and compete for the same resource; the uneven
-      // pair stays out of phase (B = 256: 96/160 1.199 ms vs 128/128 1.215 ms, same-run A/B; "split" overrides).
+      // two halves (B = 256: 96/160 1.199 ms vs 128/128 1.215 ms, same-run A/B in r02; "split" overrides).  r03 time line
+      // (option profile = 2, tools/slice_timeline.py): the two slices walk the same layers side by side and finish within
+      // microseconds of each other -- the uneven sizes change the tile counts that share the chip, not the phase.
       int first = e->opt_split > 100 ? e->opt_split - 100 : (int)((long)batch * e->opt_split / 100);
       if (e->opt_split == 0) first = batch >= 128 ? (batch * 3 / 8) & ~7 : batch / 2;
       first = std::max(1, std::min(batch - 1, first));
       start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
     }
-    rc_all = run_slice(e, x_dev, in_format, start, cnt, e->side[s], false, head, r9_dev, R_dev, po);
+    e->mark_slice = s;
+    rc_all = run_slice(e, x_dev, in_format, start, cnt, e->side[s], e->opt_profile == 2, head, r9_dev, R_dev, po);
   }
   // join every stream that was forked -- also after a failed launch, so that work already queued on the side
   // streams stays ordered before the caller's next use of x / r9 / R / Rt
@@ -973,6 +982,23 @@ extern "C" int flope_profile_read(flope_handle e, float* ms_out, int cap) {
   HIP_TRY(e, hipEventSynchronize(e->ev[e->ev_n - 1]));
   const int n = std::min(cap, e->ev_n - 1);
   for (int i = 0; i < n; ++i) HIP_TRY(e, hipEventElapsedTime(&ms_out[i], e->ev[i], e->ev[i + 1]));
+  return n;
+}
+
+// profile = 2: the last forward as it ran in production (slices on their own streams), as a time line: event i was recorded on
+// slice slice_out[i]'s stream in front of that slice's next launch (behind its last one), ms_out[i] = milliseconds since the fork.
+// Event 0 is the fork itself.  Returns the number of events.
+extern "C" int flope_profile_timeline(flope_handle e, float* ms_out, int* slice_out, int cap) {
+  if (!e || !ms_out || !slice_out) return fail(e, FLOPE_EINVAL, "flope_profile_timeline: NULL argument");
+  if (e->opt_profile != 2 || e->ev_n < 2) return fail(e, FLOPE_ESTATE, "flope_profile_timeline: no forward with option profile = 2");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipDeviceSynchronize());
+  const int n = std::min(cap, e->ev_n);
+  for (int i = 0; i < n; ++i) {
+    ms_out[i] = 0.f;
+    if (i > 0) HIP_TRY(e, hipEventElapsedTime(&ms_out[i], e->ev[0], e->ev[i]));
+    slice_out[i] = e->ev_slice[i];
+  }
   return n;
 }
 

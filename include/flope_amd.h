@@ -167,6 +167,10 @@ int flope_forward_launches(flope_handle h);
  * last event and writes the GPU time (ms) of each launch of the most recent forward; returns
  * the number written or <0.  flope_launch_info: "layer|kernel" label and algorithmic FLOPs. */
 int flope_profile_read(flope_handle h, float* ms_out, int cap);
+/* option "profile" = 2: the last forward with its batch slices on their own streams, as in production, as a time line: event i was
+ * recorded on slice slice_out[i]'s stream in front of that slice's next launch (behind its last one); ms_out[i] = milliseconds since the
+ * fork (event 0).  Returns the number of events, < 0 on error.  Developer aid (tools/slice_timeline.py). */
+int flope_profile_timeline(flope_handle h, float* ms_out, int* slice_out, int cap);
 int flope_launch_info(flope_handle h, int idx, int batch, char* name, int name_cap, double* flops);
 /* human-readable launch plan (one line per conv: tile config, patch/gather, LDS bytes) */
 int flope_describe_plan(flope_handle h, char* buf, int buflen);
