@@ -103,7 +103,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_head_fuse = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_head_fuse = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -145,6 +145,12 @@ int fail(flope_engine* e, int code, const std::string& msg) {
       HIP_TRY(e, hipEventRecord((e)->ev[(e)->ev_n++], (hipStream_t)(stream)));             \
     }                                                                                      \
   } while (0)
+
+// option "lag": one wave that sleeps ~us microseconds at the head of the last slice's stream (bounded by the real-time clock)
+__global__ void lag_kernel(int us) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
 
 int out_dim(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
@@ -531,6 +537,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
   else if (!strcmp(name, "w4mtlo")) { prev = e->opt_w4mtlo; e->opt_w4mtlo = value <= 0 ? 0 : (value < 4 ? 4 : (value > 8 ? 8 : value)); return prev; }   // smallest tile height the per-launch choice may take (0: 7 with two slices in flight, 5 alone)
+  else if (!strcmp(name, "lag")) { prev = e->opt_lag; e->opt_lag = value < 0 ? 0 : (value > 500 ? 500 : value); return prev; }   // microseconds by which the last batch slice starts late (default 20; 0 = off)
   else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value >= 4 && value <= 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 4..8 = 128..256 pixels (where the shape has that instantiation)
   else if (!strcmp(name, "head_fuse")) { prev = e->opt_head_fuse; e->opt_head_fuse = value != 0; return prev; }   // avgpool + fc.0 in one launch (bit-identical to the two)
   else if (!strcmp(name, "fc2_k4")) { prev = e->opt_fc2_k4; e->opt_fc2_k4 = value != 0; return prev; }            // fc_rot: K split over the four waves of a workgroup per image
@@ -879,6 +886,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   int rc_all = FLOPE_OK, forked = 0;
   for (int s = 0; s < ns && rc_all == FLOPE_OK; ++s) {
     if (hipStreamWaitEvent(e->side[s], e->ev_fork, 0) != hipSuccess) { rc_all = fail(e, FLOPE_EHIP, "hipStreamWaitEvent(fork) failed"); break; }
+
     forked = s + 1;
     // slice boundaries on multiples of 8 images (whole tiles in every layer) when the batch allows it
     auto bound = [&](int k) { const int b_ = (int)((long)batch * k / ns); return (batch >= 16 * ns && k > 0 && k < ns) ? ((b_ + 4) & ~7) : b_; };
@@ -894,6 +902,10 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
       start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
     }
     e->mark_slice = s;
+    // the last slice starts ~20 us late (one sleeping wave): the time line (profile = 2) shows the slices walking the same layers
+    // side by side, every pair of launches starting in the same microsecond -- i.e. their prologue fills and epilogue drains
+    // coincide; a small offset is +0.7 .. +1.4 % on the step (5 .. 30 us all do; 80 us and more lose: profiles/r03_slice_lag.txt)
+    if (e->opt_lag && s == ns - 1) hipLaunchKernelGGL(lag_kernel, dim3(1), dim3(64), 0, e->side[s], e->opt_lag);
     rc_all = run_slice(e, x_dev, in_format, start, cnt, e->side[s], e->opt_profile == 2, head, r9_dev, R_dev, po);
   }
   // join every stream that was forked -- also after a failed launch, so that work already queued on the side
