@@ -21,8 +21,15 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-$(HARNESS): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack.h
+$(HARNESS): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack.h $(CSRC)/w4_sched.h
 	g++ -O2 -fPIC -shared -std=c++17 -I$(CSRC) -o $@ $<
+
+# the same host code under AddressSanitizer + UBSan (sanitizers run on the CPU build only):
+#   make asan && LD_PRELOAD=$$(gcc -print-file-name=libasan.so) FLOPE_HOST_HARNESS=tests/host_harness/libflope_host_harness_asan.so python -m pytest tests/test_host.py -q -k harness
+HARNESS_ASAN := tests/host_harness/libflope_host_harness_asan.so
+$(HARNESS_ASAN): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack.h $(CSRC)/w4_sched.h
+	g++ -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -fPIC -shared -std=c++17 -I$(CSRC) -o $@ $<
+asan: $(HARNESS_ASAN)
 
 # diagnostic build (ablation bits + in-kernel clock stamps of conv_stag; results of dbg options are wrong by construction):
 #   make dbg && FLOPE_AMD_LIB=build/dbg/libflope_amd_dbg.so python tools/clock_probe.py
@@ -53,4 +60,4 @@ build/dma_issue_probe: tools/probes/dma_issue_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 tools: $(TOOLBINS)
 
-.PHONY: all clean dbg tools
+.PHONY: all clean dbg tools asan

@@ -155,6 +155,7 @@ struct ConvP {
   int prio;            // conv_stag: 1 = s_setprio 1 for waves 4..7, 2 = for waves 0..3, 0 = none
   int dbg_lds_off;     // diagnostic builds, dbg & 128: LDS byte offset of the stamp area (behind the kernel's own image)
   unsigned mg_pitch, sh_pitch;   // conv_w4: n / (Wip + 2) as multiply-shift (the skewed patch image's row pitch in pixels)
+  int cw_imgs;         // conv_w4 class walk (persistent workgroups): images a workgroup advances per tile of its walk (0: one tile per workgroup)
 };
 
 // Stem: 7x7 s2 p3 conv, Cin 3 (stored as 4) -> 64, + folded BN + ReLU

@@ -14,29 +14,40 @@
 //     the second fragment register set -- no partner wave, no load half;
 //   * ONE barrier per double step (64 MFMAs per wave), in the middle of it: the wave waits for its DMA pieces of the next
 //     double tile (counted vmcnt), then the barrier publishes them; the reads of the following sub-step come after it.
-// Same LDS images (conflict-free patch image of conv_stag r03, weight ring of double tiles), same packed weights, same
-// register epilogue (lane = one pixel x 16 channels in two runs of 8), same folded 1x1 stride-2 shortcut, residual by
-// LDS-DMA in the slots the look-ahead of the last body leaves unused.  One tile per workgroup (a persistent tile walk exists as the
-// measured-slower option PERS); split-K stays on conv_stag.  The tile HEIGHT is a template argument (MT = 8..4 pixel
-// tiles of 16 per wave = 256..128-pixel workgroup tiles): the engine picks it per launch by whole rounds of the chip (DESIGN.md
-// 9.7b) -- every height runs the same MFMA sequence per output, so all of them are bit-identical.
+// Same LDS images (conflict-free patch image of conv_stag r03, weight ring of double tiles), same packed weights, same folded 1x1
+// stride-2 shortcut, residual by LDS-DMA in the slots the look-ahead of the last body leaves unused.  The tile HEIGHT is a template
+// argument (MT = 8..4 pixel tiles of 16 per wave = 256..128-pixel workgroup tiles): the engine picks it per launch by whole rounds
+// of the chip -- every height runs the same MFMA sequence per output, so all of them are bit-identical.
+//
+// r04:
+//   * PERS = a CLASS WALK.  A workgroup walks M tiles mt, mt + G, mt + 2 G, ... where G tiles are a whole number of images
+//     (p.cw_imgs), so every tile of its walk has the same geometry relative to its patch origin: the fragment address table is
+//     built ONCE, a tile boundary is {epilogue, uniform pointer bumps, accumulators back to the bias}.  The step stream does not
+//     stop at the boundary: the weight ring wraps to the start of the panel (= the next tile's first double tiles), the patch
+//     burst of double step 5 of a tile's last body fetches the NEXT tile's first half-chunk, and the fragments the last
+//     sub-step prefetches ARE the next tile's first (same table).  r03's persistent form recomputed the table at every
+//     boundary (3.7-5.3 k cycles of a 10.8 k boundary against 15 k for a fresh workgroup: measured slower).
+//     Residual inputs of persistent tiles come by register loads during the last body (their LDS-DMA slots carry the next
+//     tile's data).
+//   * LINE-ORDER stores.  The MFMA accumulator layout gives a lane one pixel x two runs of 8 channels, so a wave-store touched 16
+//     pixels x 64 bytes; the store path takes ~66 cycles per such instruction (64 per workgroup tile = 4.2 k cycles, measured:
+//     tools/probes/store_probe.hip, profiles/r04_store_probe.txt).  The packed outputs now pass through a wave-private 2 KB LDS
+//     image (XOR-swizzled, conflict-free both ways) and leave as 8 whole 128-byte lines per instruction: 2.9 k cycles.  Only the
+//     order of the stores changes -- same bytes, same addresses.  (-DFLOPE_W4_MFMA_STORES builds the r03 order for A/B runs.)
 #include "common.h"
+#include "w4_sched.h"
+#ifndef FLOPE_W4_SPREAD
+#define FLOPE_W4_SPREAD 2
+#endif
 
-// LDS-DMA, optionally (FLOPE_W4_ASM_DMA) as inline assembly hidden from hipcc's wait-count pass.  While that pass knows of one outstanding flat-encoded access that
-// may land in LDS (its "pending flat" state; global_load_lds counts as one) it forces every wait it inserts to 0: lgkmcnt(0) in
-// front of each sub-step's first MFMA (instead of counting the younger fragment reads it may leave in flight) and vmcnt(0) at the
-// first use of any ordinary load.  This kernel counts its DMAs itself (W4_WAIT_VM); the "memory" clobber keeps every ds_read /
-// ds_write on its side of a DMA in program order.
-#pragma clang diagnostic ignored "-Winline-asm"
-#ifndef FLOPE_W4_ASM_DMA         // the compiler-visible form (default: measured 1.5-2.5 % faster per conv than the hidden one)
+// LDS-DMA in the compiler-visible form.  While hipcc's wait-count pass knows of one outstanding flat-encoded access that may land in
+// LDS (global_load_lds counts as one) it forces every wait it inserts to 0: lgkmcnt(0) in front of each sub-step's first MFMA and
+// vmcnt(0) at the first use of any ordinary load -- so this kernel counts its DMAs itself (W4_WAIT_VM) and keeps ordinary loads out
+// of the loop (r03 also built the DMAs as inline assembly hidden from that pass: exact lgkmcnt waits, 1.5-2.5 % slower per conv
+// for the s_nop + s_mov m0 per piece; removed in r04).
 #define GLDS16(gptr, lptr)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-#else
-#define GLDS16(gptr, lptr)                                                                                     \
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"((const char*)(gptr)),   \
-               "s"((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lptr)) : "memory", "m0")
-#endif
 
 __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 12 ? 2 * (c - 4) + 1 : 2 * (c - 8)); }
 
@@ -47,14 +58,10 @@ __device__ __forceinline__ int tile_px_w4(int c) { return c < 4 ? 2 * c : (c < 1
 // (r03: loading the table from memory instead -- precomputed per tile geometry class, 49 classes x 20 KiB per conv, 20 coalesced
 // 16-byte loads per lane -- was measured and dropped: the loads took 10-12 k cycles against 5 k for computing it, the tables do not
 // stay in L2 between tiles; step 1.116 vs 1.094 ms in same-run A/B.)
-// PT: 8 KB DMA rounds per patch buffer (4, 5 or 6).  NBD: double tiles in the weight ring (3, 4 or 5; the DMA runs NBD - 1
-// double steps ahead of its consumer).  MT: pixel tiles per wave (8..4; below 7 only PT = 4, NBD = 5 are instantiated).  RES: residual input.  DSF: folded 1x1 stride-2 shortcut (no residual).
-// PERS (no residual input): at most one workgroup per CU walks M tiles mt, mt + G, ... of its channel tile.  The step stream does
-// not stop at a tile boundary: the weight ring wraps to the start of the panel (= the next tile's first double tiles) and the
-// patch burst of double step 5 of a tile's last body fetches the NEXT tile's first half-chunk -- r03 stamps: of the 9-10 k cycles a
-// tile spends before its first MFMA, ~5 k are nothing but the flight time of its first DMAs; only the epilogue, the next tile's
-// address table (~1 k cycles) and the folded shortcut sit between two tiles.
-template <typename T, int PT, bool RES, bool DSF, int NBD, bool PERS, int MT>
+// PT: 8 KB DMA rounds per patch buffer (4, 5 or 6); the weight ring holds NBD = w4_ring(PT, ..) double tiles (the DMA runs NBD - 1
+// double steps ahead of its consumer).  MT: pixel tiles per wave (8..4; below 7 only PT = 4).  RES: residual input.  DSF: folded
+// 1x1 stride-2 shortcut (no residual).  PERS: class walk (header; MT = 7 only).
+template <typename T, int PT, bool RES, bool DSF, bool PERS, int MT>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   typedef typename Elem<T>::frag frag;
   // MT = pixel tiles of 16 per wave: 8 -> 256-pixel workgroup tiles; 7 -> 224 (r03c: 224 divides the 28 x 28, 14 x 14 and 7 x 7
@@ -62,18 +69,21 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // 6, 5, 4 -> 192, 160, 128: launches of fewer than ~200 tiles (layer 4, batch slices) fill more of the chip with smaller ones
   constexpr int BM = 2 * MT * 16, WPXB = MT * 16, TILE_B = 128 * 64, DT_B = 2 * TILE_B, NT = 4;
   static_assert(MT >= 4 && MT <= 8, "conv_w4: 4..8 pixel tiles per wave");
+  constexpr int NBD = w4_ring(PT, DSF && PERS);
+  static_assert(NBD >= 3, "conv_w4: this variant does not fit the CU's LDS");
   constexpr int PATCH_B = PT * 8192;
   constexpr int PD = NBD - 1;                              // double tiles in flight ahead of the one being consumed
-  constexpr int TGW = DT_B / 4096;                         // LDS-DMA ops per wave per double tile (4)
+  constexpr int TGW = W4_TGW;                              // LDS-DMA ops per wave per double tile (4)
   constexpr int PW = 2 * PT;                               // ... per patch burst
-  static_assert(!(RES && DSF) && !(RES && PERS) && PT >= 4 && NBD >= 3 && NBD <= 5, "conv_w4 variants");
+  constexpr int SPREAD = FLOPE_W4_SPREAD;                  // parts the cold patch burst is issued in (w4_sched.h)
+  static_assert(!(RES && DSF) && PT >= 4 && !(PERS && MT != 7), "conv_w4 variants");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;                                   // 2 patch buffers
   char* const Bs = smem + 2 * PATCH_B;                     // NBD double tiles of weights
   // DSF: the shortcut's double tile of weights.  One tile per workgroup: the ring's last look-ahead slot, idle until the first
   // body double step issues into it.  PERS: at a tile boundary every ring slot is in flight -> a slot of its own behind the ring.
   constexpr int DSW_B = (PERS ? NBD : NBD - 1) * DT_B;
-  constexpr int SCR_B = 2 * PATCH_B + NBD * DT_B + (DSF && PERS ? DT_B : 0);   // 12.5 KB: address-table exchange
+  constexpr int SCR_B = 2 * PATCH_B + NBD * DT_B + (DSF && PERS ? DT_B : 0);   // 12.5 KB: address-table exchange, then the epilogue's line image
 
 #ifdef FLOPE_STAG_DBG
   // diagnostic build, dbg & 64: shader-clock stamps {entry, loop start, loop end, exit} + 100 MHz real time {loop start, loop end}
@@ -85,11 +95,17 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #define W4_PSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); st_p[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
   // per double step of the LAST body: lane 2 D = clock in front of the DMA wait, lane 2 D + 1 = behind the barrier (one VGPR)
   unsigned st_v = 0;
-#define W4_DSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); { const unsigned lo_ = (unsigned)__builtin_amdgcn_s_memtime(); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(st_v) : "s"(lo_), "n"(i_)); } __builtin_amdgcn_sched_barrier(0); } while (0)
+  // (dbg & 256: of the FIRST body of the workgroup's second tile instead -- class walk -- or, one tile per workgroup, of its first body)
+#define W4_DSTAMP(i_) do { __builtin_amdgcn_sched_barrier(0); if ((p.dbg & 256) ? (hc == 0 && st_tile == (PERS ? 1 : 0)) : lastb_) { const unsigned lo_ = (unsigned)__builtin_amdgcn_s_memtime(); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(st_v) : "s"(lo_), "n"(i_)); } __builtin_amdgcn_sched_barrier(0); } while (0)
+  // dbg & 512: inside double step 6 / 7 of the same body, a stamp behind every MFMA group of the second sub-step of D = 6 (lanes 0..7)
+  // and of the first sub-step of D = 7 (lanes 8..15)
+  unsigned st_w = 0;
+#define W4_GSTAMP(i_) do { if (p.dbg & 512) { __builtin_amdgcn_sched_barrier(0); if ((p.dbg & 256) ? (hc == 0 && st_tile == (PERS ? 1 : 0)) : lastb_) { const unsigned lo_ = (unsigned)__builtin_amdgcn_s_memtime(); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(st_w) : "s"(lo_), "n"(i_)); } __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define W4_PSTAMP(i_) do {} while (0)
 #define W4_BSTAMP(i_) do {} while (0)
 #define W4_DSTAMP(i_) do {} while (0)
+#define W4_GSTAMP(i_) do {} while (0)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,17 +123,18 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   const int pitch = p.Wip + 2;                             // conflict-free patch image (conv_stag.hip, r03)
 
   int mt = lb / p.ntiles;                                  // this workgroup's current M tile
-  const int G_mt = gridDim.x / p.ntiles;                   // PERS: stride of its walk (the grid is a multiple of ntiles)
-  int m0, mend, R0;
+  const int G_mt = gridDim.x / p.ntiles;                   // PERS: stride of its walk (the grid is a multiple of ntiles; G_mt tiles = p.cw_imgs images)
+  const int m0 = mt * BM, mend = min(m0 + BM, p.M);        // the FIRST tile (PERS: every tile is whole and has its geometry)
+  int R0;
   const char* patch_src;
-#define W4_GEOM(mt_, m0_, mend_, R0_, src_)                                                                    \
-  do {                                                                                                         \
-    m0_ = (mt_) * BM; mend_ = min(m0_ + BM, p.M);                                                              \
-    const int b0_ = fastdiv(m0_, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0_ - b0_ * HoWo, p.mg_w, p.sh_w);          \
-    R0_ = b0_ * p.Hip + ho0_;                                                                                  \
-    src_ = (const char*)p.in + (size_t)R0_ * rowB;                                                             \
-  } while (0)
-  W4_GEOM(mt, m0, mend, R0, patch_src);
+  {
+    const int b0_ = fastdiv(m0, p.mg_hw, p.sh_hw), ho0_ = fastdiv(m0 - b0_ * HoWo, p.mg_w, p.sh_w);
+    R0 = b0_ * p.Hip + ho0_;
+    patch_src = (const char*)p.in + (size_t)R0 * rowB;
+  }
+  // PERS: what one step of the walk (p.cw_imgs images) adds to the pointers
+  const size_t d_patch = PERS ? (size_t)p.cw_imgs * p.Hip * rowB : 0;
+  const unsigned d_out = PERS ? (unsigned)((size_t)p.cw_imgs * p.Hop * p.Wop * p.Cout * 2) : 0u;
 
   const char* const b_base = (const char*)p.w + (size_t)ntile * NS * TILE_B + wave * 1024 + lane * 16;
   const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
@@ -177,23 +194,21 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     _Pragma("unroll") for (int o = 0; o < TGW; ++o)                                                            \
       GLDS16(dw_base + (size_t)(j_) * DT_B + o * 4096, Bs + DSW_B + o * 4096 + wave * 1024);                   \
   } while (0)
-#define W4_DS_SOURCES()   /* this lane's four gather sources of the current tile */                            \
-  do {                                                                                                         \
-    const size_t dpix = (size_t)p.ds_Cin * 2;                                                                  \
-    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                         \
-      const int q = rr * 256 + wave * 64 + lane, sl = q >> 2;                                                  \
-      const int m = min(m0 + sl, mend - 1);                                                                    \
-      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;                                         \
-      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;                                      \
-      dsrc[rr] = (const char*)p.ds_in + (((size_t)b_ * p.ds_Hip + 2 * ho_ + 1) * p.ds_Wip + 2 * wo_ + 1) * dpix + \
-                 (((q & 3) ^ ((sl >> 2) & 3)) << 4);                                                           \
-    }                                                                                                          \
-  } while (0)
   if constexpr (DSF) {
-    W4_DS_SOURCES();
+    const size_t dpix = (size_t)p.ds_Cin * 2;              // this lane's four gather sources of the first tile
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int q = rr * 256 + wave * 64 + lane, sl = q >> 2;
+      const int m = min(m0 + sl, mend - 1);
+      const int b_ = fastdiv(m, p.mg_hw, p.sh_hw), r_ = m - b_ * HoWo;
+      const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - ho_ * p.Wo;
+      dsrc[rr] = (const char*)p.ds_in + (((size_t)b_ * p.ds_Hip + 2 * ho_ + 1) * p.ds_Wip + 2 * wo_ + 1) * dpix +
+                 (((q & 3) ^ ((sl >> 2) & 3)) << 4);
+    }
     dw_base = (const char*)p.ds_w + (size_t)ntile * (p.ds_Cin / 32) * TILE_B + wave * 1024 + lane * 16;
     W4_ISSUE_DS(0);
   }
+  const size_t d_ds = (PERS && DSF) ? (size_t)p.cw_imgs * p.ds_Hip * p.ds_Wip * p.ds_Cin * 2 : 0;
 
   // per-lane DMA source offsets of a patch burst: op j = 2 rr + h moves pieces rr * 512 + h * 256 + wave * 64 + lane
   unsigned psrc[PW];
@@ -208,58 +223,80 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   W4_ISSUE_PATCH(patch_src, 0);
   W4_PSTAMP(1);
 
-  // Fragment address table xoff[t][pt] and output offsets ooff[pt].  Eight lanes of the workgroup -- the four k-slots g of a pixel
+  // Fragment address table xoff[t][pt] and output offsets.  Eight lanes of the workgroup -- the four k-slots g of a pixel
   // column, in both channel-half waves -- need the same 8 x 9 offsets up to a final `^ (g << 4)` / `+ channel block`: each of the
   // eight computes ONE pixel tile (a fastdiv chain + 9 entries, ~60 vector instructions instead of ~700) and they trade through 12 KB
   // of LDS behind the weight ring (r03 stamps: the table was 3-5 k cycles of a 9-10 k-cycle prologue in which the matrix pipe idles).
+  // Output offsets come in two orders: ooff[pt] = this lane's own pixel (MFMA order; RES only: where its residual lives) and
+  // osto[pt][c] = pixel c * 8 + (lane >> 3) of the tile's LDS line image, 16-byte chunk lane & 7 of the wave's 128 bytes (line order).
   int xoff[9][MT];
-  unsigned ooff[MT];
-  bool ok[MT];
-#define W4_TABLE()                                                                                             \
-  do {                                                                                                         \
-    /* [wpx][r16][pt][12 dwords], 400 B (25 bank quads, odd) per r16: the 16 pixel columns of a ds_read_b128 lane group land on \
-       16 different quads (at 384 B they fell on two: the reads below were 8-way conflicts, r03a counters) */   \
-    char* const scr = smem + SCR_B + (wpx * 16 + r16) * 400;                                                   \
-    const int ptm = wch * 4 + g;                                      /* the pixel tile this lane computes */  \
-    const int mm = m0 + wpx * WPXB + ptm * 16 + pcol;                                                          \
-    const int m_ = min(mm, mend - 1);                                                                          \
-    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo);                                 \
-    const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);                                \
-    const int i_ = __mul24(b_, p.Hip) + ho_ - R0;                                                              \
-    const int pb = (__mul24(i_, pitch) + wo_) << 6, vb = (__mul24(i_, p.Wo) + wo_) << 2;                       \
-    u32x4 e0, e1, e2;                                                                                          \
-    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                            \
-      const unsigned v = (unsigned)(pb + (((t / 3) * pitch + (t % 3)) << 6) + ((vb + (((t / 3) * p.Wo + (t % 3)) << 2)) & 0x30)); \
-      if (t < 4) e0[t] = v; else if (t < 8) e1[t - 4] = v; else e2[0] = v;                                     \
-    }                                                                                                          \
-    e2[1] = (unsigned)(__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) * 2);           \
-    e2[2] = 0u; e2[3] = 0u;                                                                                    \
-    *(u32x4*)(scr + ptm * 48) = e0; *(u32x4*)(scr + ptm * 48 + 16) = e1; *(u32x4*)(scr + ptm * 48 + 32) = e2;  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the LDS writes are done before the barrier lets the readers go (no vmcnt: the DMAs stay in flight) */ \
-    W4_BARRIER();                                                                                              \
-    const unsigned g4 = (unsigned)(g << 4);                                                                    \
-    _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) {                                                        \
-      const u32x4 a0 = *(const u32x4*)(scr + pt * 48), a1 = *(const u32x4*)(scr + pt * 48 + 16), a2 = *(const u32x4*)(scr + pt * 48 + 32); \
-      _Pragma("unroll") for (int t = 0; t < 4; ++t) { xoff[t][pt] = (int)(a0[t] ^ g4); xoff[4 + t][pt] = (int)(a1[t] ^ g4); } \
-      xoff[8][pt] = (int)(a2[0] ^ g4);                                                                         \
-      ooff[pt] = a2[1] + (unsigned)(cb * 2);                                                                   \
-      ok[pt] = m0 + wpx * WPXB + pt * 16 + pcol < mend;                                                        \
-    }                                                                                                          \
-  } while (0)
-  W4_TABLE();
+  unsigned ooff[RES ? MT : 1];
+  unsigned osto[MT][2];
+  bool okl[MT][2];
+  {
+    /* [wpx][r16][pt][12 dwords], 400 B (25 bank quads, odd) per r16: the 16 pixel columns of a ds_read_b128 lane group land on
+       16 different quads (at 384 B they fell on two: the reads below were 8-way conflicts, r03a counters) */
+    char* const scr = smem + SCR_B + (wpx * 16 + r16) * 400;
+    const int ptm = wch * 4 + g;                                      /* the pixel tile this lane computes */
+    const int mm = m0 + wpx * WPXB + ptm * 16 + pcol;
+    const int m_ = min(mm, mend - 1);
+    const int b_ = fastdiv(m_, p.mg_hw, p.sh_hw), r_ = m_ - __mul24(b_, HoWo);
+    const int ho_ = fastdiv(r_, p.mg_w, p.sh_w), wo_ = r_ - __mul24(ho_, p.Wo);
+    const int i_ = __mul24(b_, p.Hip) + ho_ - R0;
+    const int pb = (__mul24(i_, pitch) + wo_) << 6, vb = (__mul24(i_, p.Wo) + wo_) << 2;
+    u32x4 e0, e1, e2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const unsigned v = (unsigned)(pb + (((t / 3) * pitch + (t % 3)) << 6) + ((vb + (((t / 3) * p.Wo + (t % 3)) << 2)) & 0x30));
+      if (t < 4) e0[t] = v; else if (t < 8) e1[t - 4] = v; else e2[0] = v;
+    }
+    e2[1] = (unsigned)(__mul24(__mul24(__mul24(b_, p.Hop) + ho_ + 1, p.Wop) + wo_ + 1, p.Cout) * 2);
+    e2[2] = 0u; e2[3] = 0u;
+    *(u32x4*)(scr + ptm * 48) = e0; *(u32x4*)(scr + ptm * 48 + 16) = e1; *(u32x4*)(scr + ptm * 48 + 32) = e2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the LDS writes are done before the barrier lets the readers go (no vmcnt: the DMAs stay in flight) */
+    W4_BARRIER();
+    const unsigned g4 = (unsigned)(g << 4);
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) {
+      const u32x4 a0 = *(const u32x4*)(scr + pt * 48), a1 = *(const u32x4*)(scr + pt * 48 + 16);
+      const u32x2 a2 = *(const u32x2*)(scr + pt * 48 + 32);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { xoff[t][pt] = (int)(a0[t] ^ g4); xoff[4 + t][pt] = (int)(a1[t] ^ g4); }
+      xoff[8][pt] = (int)(a2[0] ^ g4);
+      if constexpr (RES) ooff[pt] = a2[1] + (unsigned)(cb * 2);
+      // line order: row pp = c * 8 + (lane >> 3) of the line image is written by the lanes with r16 = pp, i.e. it holds the pixel
+      // whose table entry sits at (wpx, pp)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#ifdef FLOPE_W4_MFMA_STORES
+        osto[pt][c] = a2[1] + (unsigned)(cb * 2 + c * 64);
+        okl[pt][c] = PERS || (m0 + wpx * WPXB + pt * 16 + pcol < mend);
+#else
+        const int pp = c * 8 + (lane >> 3);
+        osto[pt][c] = *(const unsigned*)(smem + SCR_B + (wpx * 16 + pp) * 400 + pt * 48 + 36) +
+                      (unsigned)((ntile * 128 + wch * 64) * 2 + (lane & 7) * 16);
+        okl[pt][c] = PERS || (m0 + wpx * WPXB + pt * 16 + tile_px_w4(pp) < mend);
+#endif
+      }
+    }
+  }
 
   // pin the tables in FRONT of the DMA wait (left alone, the compiler sinks these ~800 pure vector instructions behind the wait
   // and the barrier, next to their first use -- the DMA flight time and the table time then add up instead of overlapping)
 #pragma unroll
   for (int t = 0; t < 9; ++t)
-    asm volatile("" ::"v"(xoff[t][0]), "v"(xoff[t][1]), "v"(xoff[t][2]), "v"(xoff[t][3]), "v"(xoff[t][4]), "v"(xoff[t][5]), "v"(xoff[t][6]), "v"(xoff[t][7]));
-  asm volatile("" ::"v"(ooff[0]), "v"(ooff[1]), "v"(ooff[2]), "v"(ooff[3]), "v"(ooff[4]), "v"(ooff[5]), "v"(ooff[6]), "v"(ooff[7]));
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) asm volatile("" ::"v"(xoff[t][pt]));
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) asm volatile("" ::"v"(osto[pt][0]), "v"(osto[pt][1]));
   __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[MT][NT];
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-    for (int pt = 0; pt < MT; ++pt) acc[pt][ct] = b4[ct];
+#define W4_ACC_INIT()                                                                                          \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
+      _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) acc[pt][ct] = b4[ct];                                  \
+  } while (0)
+  W4_ACC_INIT();
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt)                          // ... and the accumulator init too (128 register moves)
     asm volatile("" : "+a"(acc[pt][0]), "+a"(acc[pt][1]), "+a"(acc[pt][2]), "+a"(acc[pt][3]));
@@ -305,24 +342,27 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) xf[0][pt] = *(const frag*)(smem + xoff[0][pt]);
 
+  // PERS + RES: the tile's residual, 2 MT 16-byte loads per lane into ACCUMULATOR registers (the loop has no arch VGPR to spare: 256
+  // is the encoding's limit) in MFMA order (the lane's own pixel), issued by inline
+  // assembly in the first sub-steps of double steps 7 and 8 of the last body (hidden from hipcc's wait-count pass, which would answer
+  // an ordinary load among LDS-DMAs with vmcnt(0) at its first use): counted in W4_DSTEP's waits (w4_sched.h), complete behind
+  // the epilogue's own vmcnt(TGW)
+  u32x4 rq[(RES && PERS) ? MT : 1][2];
+  const char* const res_b = (const char*)p.res;
+
   // One sub-step: the 32 MFMAs of fragment set C_ with the 12 fragment reads of the NEXT sub-step (set N_: weights at LDS
   // byte offset wo_, pixel fragments of patch buffer nb_ / tap nt_) issued in their gaps, 4 weight fragments first, and -- in
   // the second sub-step of a double step -- this wave's LDS-DMA pieces (DMA_(i): piece i of the double step's NV_ pieces, KV_ per
   // group of 4 MFMAs; an LDS-DMA issue costs ~60 cycles of the wave's issue time among MFMAs: spread out, never in front of
   // them).  Program order IS the wanted order (the compiler keeps LDS-DMA and ds_read in program order: both touch LDS);
-  // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.
-#define W4_NODMA(i_) do {} while (0)
-#define W4_G0(NV_, KV_) 0        /* first MFMA group that carries DMA pieces (placing them in the LAST groups measured -0.5 %) */
-#ifndef FLOPE_W4_ASM_DMA
+  // sched_group_barrier pins the {4 MFMA, 2 reads, KV_ DMA} x 8 interleave.  VG_ = 0: the pieces are inline-assembly loads (the
+  // residual of a persistent tile), which the scheduler does not class as VMEM: no VMEM group.
 #define W4_VMEM_GROUP(P_, NV_, KV_)                                                                            \
   do {                                                                                                         \
     if constexpr ((KV_) > 0 && (P_) * (KV_) < (NV_))                                                           \
       __builtin_amdgcn_sched_group_barrier(0x020, (((P_) + 1) * (KV_) <= (NV_) ? (KV_) : (NV_) - (P_) * (KV_)), 0); \
   } while (0)
-#else
-#define W4_VMEM_GROUP(P_, NV_, KV_) do {} while (0)         /* an inline-assembly DMA stays where the program put it */
-#endif
-#define W4_GRP(P_, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                      \
+#define W4_GRP(P_, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_)                                                 \
   do {                                                                                                         \
     if constexpr ((P_) < MT) {                             /* MT = 7: the eighth group does not exist */          \
       _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                        \
@@ -332,25 +372,25 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
         wf[N_][2 * (P_)] = *(const frag*)(smem + (wo_) + (2 * (P_)) * 1024);                                   \
         wf[N_][2 * (P_) + 1] = *(const frag*)(smem + (wo_) + (2 * (P_) + 1) * 1024);                           \
       } else if constexpr ((P_) < 6) {                                                                         \
-        if constexpr (X0_ < MT) xf[N_][X0_] = *(const frag*)(smem + xoff[nt_][X0_] + (nb_) * PATCH_B);         \
-        if constexpr (X1_ < MT) xf[N_][X1_] = *(const frag*)(smem + xoff[nt_][X1_] + (nb_) * PATCH_B);         \
+        if constexpr (X0_ < MT) xf[N_][X0_ < MT ? X0_ : 0] = *(const frag*)(smem + xoff[nt_][X0_ < MT ? X0_ : 0] + (nb_) * PATCH_B); \
+        if constexpr (X1_ < MT) xf[N_][X1_ < MT ? X1_ : 0] = *(const frag*)(smem + xoff[nt_][X1_ < MT ? X1_ : 0] + (nb_) * PATCH_B); \
       }                                                                                                        \
-      constexpr int Q_ = (P_) - W4_G0(NV_, KV_);           /* the DMA group index of this MFMA group (< 0: none yet) */ \
-      if constexpr ((KV_) > 0 && Q_ >= 0 && Q_ * (KV_) + 0 < (NV_)) DMA_((Q_ * (KV_) + 0));                    \
-      if constexpr ((KV_) > 1 && Q_ >= 0 && Q_ * (KV_) + 1 < (NV_)) DMA_((Q_ * (KV_) + 1));                    \
-      if constexpr ((KV_) > 2 && Q_ >= 0 && Q_ * (KV_) + 2 < (NV_)) DMA_((Q_ * (KV_) + 2));                    \
+      if constexpr ((KV_) > 0 && (P_) * (KV_) + 0 < (NV_)) DMA_(((P_) * (KV_) + 0));                           \
+      if constexpr ((KV_) > 1 && (P_) * (KV_) + 1 < (NV_)) DMA_(((P_) * (KV_) + 1));                           \
+      if constexpr ((KV_) > 2 && (P_) * (KV_) + 2 < (NV_)) DMA_(((P_) * (KV_) + 2));                           \
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                       \
       constexpr int NR_ = (P_) < 2 ? 2 : ((P_) < 6 ? (X0_ < MT ? 1 : 0) + (X1_ < MT ? 1 : 0) : 0);   /* reads of this group */ \
       if constexpr (NR_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, NR_, 0);                              \
-      if constexpr (Q_ >= 0) W4_VMEM_GROUP(Q_, NV_, KV_);                                                      \
+      if constexpr (VG_) W4_VMEM_GROUP(P_, NV_, KV_);                                                          \
+      if constexpr (((C_) == 1 && D_ == 6) || ((C_) == 0 && D_ == 7)) W4_GSTAMP(((C_) == 1 ? (P_) : 8 + (P_))); \
     }                                                                                                          \
   } while (0)
-#define W4_SUB(C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_)                                                          \
+#define W4_SUB(C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_)                                                     \
   do {                                                                                                         \
-    W4_GRP(0, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(1, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
-    W4_GRP(2, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(3, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
-    W4_GRP(4, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(5, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
-    W4_GRP(6, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_); W4_GRP(7, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_);        \
+    W4_GRP(0, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); W4_GRP(1, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); \
+    W4_GRP(2, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); W4_GRP(3, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); \
+    W4_GRP(4, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); W4_GRP(5, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); \
+    W4_GRP(6, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); W4_GRP(7, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_); \
   } while (0)
 
   int dn = PD;                                             // next double tile to issue
@@ -362,9 +402,10 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 
   // double step D of a body: sub-steps u0 = 2 D, u1 = 2 D + 1 (tap u % 9 of half-chunk u / 9); the sub-step after u1 is 2 D + 2
   // (D = 8: the next body's first).  DMA pieces of the double step: 0 .. TGW - 1 = double tile D + PD into the slot PD ahead;
-  // then, at D = 0 and D = 5, the PW pieces of a patch burst.  RES, last body: the burst of D = 5 (the next tile's patch: unused)
-  // and the double tiles of D = 7, 8 (they wrap to the start of the panel: unused) carry the tile's residual instead --
-  // 8 + 4 + 4 pieces per lane, the 16 bytes each lane adds itself in the epilogue.
+  // then, at D = 0 and D = 5, the PW pieces of a patch burst.  RES, one tile per workgroup, last body: the burst of D = 5 (the next
+  // tile's patch: unused) and the double tiles of D = 7, 8 (they wrap to the start of the panel: unused) carry the tile's residual
+  // instead -- 8 + 4 + 4 pieces per lane, the 16 bytes each lane adds itself in the epilogue.  Every wait count below comes from
+  // w4_sched.h, where the host-side schedule model (tests/host_harness, test_host.py) replays them.
 #ifdef FLOPE_STAG_DBG      /* ablation (results wrong by construction): dbg & 1 = no weight DMA in the loop, dbg & 2 = no patch DMA */
 #define W4_ABL_W if (!(p.dbg & 1))
 #define W4_ABL_P if (!(p.dbg & 2))
@@ -376,51 +417,61 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   do {                                                                                                         \
     if constexpr ((i_) < TGW) {                                                                                \
       constexpr int rpt_ = 4 + 2 * RS_ + (((i_) >> 1) & 1);   /* the pixel tile whose residual rides here (MT = 7: none for 7) */ \
-      if (RES && lastb_ && (D_ == 7 || D_ == 8) && rpt_ < MT) {                                                \
-        unsigned ro_ = ooff[rpt_ < MT ? rpt_ : 0]; asm volatile("" : "+v"(ro_));                               \
-        GLDS16((const char*)p.res + ro_ + ((i_) & 1) * 64, Bs + iss_b_ + (i_) * 4096 + wave * 1024);           \
+      if (RES && !PERS && lastb_ && (D_ == 7 || D_ == 8) && rpt_ < MT) {                                       \
+        unsigned ro_ = ooff[(RES && rpt_ < MT) ? rpt_ : 0]; asm volatile("" : "+v"(ro_));                      \
+        GLDS16(res_b + ro_ + ((i_) & 1) * 64, Bs + iss_b_ + (i_) * 4096 + wave * 1024);                        \
       } else {                                                                                                 \
         W4_ABL_W GLDS16(b_base + (size_t)di_ * DT_B + (i_) * 4096, Bs + iss_b_ + (i_) * 4096 + wave * 1024);   \
       }                                                                                                        \
     } else {                                                                                                   \
-      constexpr int j_ = (i_) - TGW < 0 ? 0 : ((i_) - TGW >= PW ? PW - 1 : (i_) - TGW);                        \
+      constexpr int jr_ = (i_) - TGW + w4_patch_first(D_, PW, SPREAD);      /* index of the piece in its burst */  \
+      constexpr int j_ = jr_ < 0 ? 0 : (jr_ >= PW ? PW - 1 : jr_);                                             \
       if (D_ == 0) {                                                                                           \
         W4_ABL_P GLDS16(patch_src + (hc + 1) * 64 + psrc[j_], Ps + PATCH_B + (j_ * 256 + wave * 64) * 16);     \
-      } else if (RES && lastb_ && j_ < 8) {                                                                    \
-        unsigned ro_ = ooff[j_ >> 1]; asm volatile("" : "+v"(ro_));                                            \
-        GLDS16((const char*)p.res + ro_ + (j_ & 1) * 64, Ps + (j_ * 256 + wave * 64) * 16);                    \
+      } else if (RES && !PERS && lastb_ && j_ < 8) {                                                           \
+        unsigned ro_ = ooff[RES ? (j_ >> 1) : 0]; asm volatile("" : "+v"(ro_));                                \
+        GLDS16(res_b + ro_ + (j_ & 1) * 64, Ps + (j_ * 256 + wave * 64) * 16);                                 \
       } else {                                                                                                 \
         W4_ABL_P GLDS16((hc + 2 < nhc ? patch_src + (hc + 2) * 64 : n_patch_src) + psrc[j_], Ps + (j_ * 256 + wave * 64) * 16); \
       }                                                                                                        \
     }                                                                                                          \
   } while (0)
+  // PERS + RES, last body: residual load i_ of the first sub-step of double step 7 (loads 0 .. 7) / 8 (8 .. 2 MT - 1)
+#define W4_RES_PIECE(i_)                                                                                       \
+  do {                                                                                                         \
+    constexpr int ri_ = (D_ == 7 ? 0 : w4_res_first(MT)) + (i_), rp_ = (ri_ >> 1) < MT ? (ri_ >> 1) : 0;      \
+    if (lastb_) {                                                                                              \
+      const char* ra_ = res_b + ooff[RES ? rp_ : 0] + (ri_ & 1) * 64;                                          \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(rq[(RES && PERS) ? rp_ : 0][ri_ & 1]) : "v"(ra_) : "memory"); \
+    }                                                                                                          \
+  } while (0)
 #define W4_DSTEP(D)                                                                                            \
   do {                                                                                                         \
     constexpr int D_ = (D), U1_ = 2 * (D) + 1, U2_ = (2 * (D) + 2) % 18, RS_ = (D) == 8 ? 1 : 0;               \
-    /* vmcnt at the barrier: everything but the ops younger than double tile D + 1 -- the PD - 2 later double tiles and a patch \
-       burst issued in the second sub-step of double step Dp in {0, 5} while D + 1 - PD <= Dp <= D - 1 */      \
-    /* (PD >= 5: a burst of D = 5 would still be younger at the NEXT body's D = 0; not counted there -- the first body has none --   \
-       which only makes that one wait stricter than it needs to be) */                                          \
-    /* ... and only while that burst is not yet due: the burst of Dp = 0 is read from sub-step 8 on (behind barrier 3), the one \
-       of Dp = 5 from sub-step 17 on (behind barrier 8) */                                                     \
-    constexpr int WN_ = TGW * (PD - 2) + ((((D) >= 1 && (D) <= PD - 1 && (D) <= 2) || ((D) >= 6 && (D) <= PD + 4 && (D) <= 7)) ? PW : 0); \
-    constexpr int NV_ = TGW + (((D) == 0 || (D) == 5) ? PW : 0), KV_ = (NV_ + MT - 1) / MT;                    \
+    /* vmcnt in front of the barrier, from the queue model (w4_sched.h): inside a tile; in the first body behind a class walk's tile \
+       boundary (E: the 2 MT epilogue stores are in the queue); in a class walk's last body with a residual input (R: its register loads) */ \
+    constexpr int WN_ = w4_wait_n(D_, PD, PW, SPREAD, 0, 0);                                                   \
+    constexpr int WNE_ = PERS ? w4_wait_n(D_, PD, PW, SPREAD, 2 * MT, 0) : WN_;                                \
+    constexpr int WNR_ = (RES && PERS) ? w4_wait_n(D_, PD, PW, SPREAD, 0, MT) : WN_;                           \
+    constexpr int WNER_ = (RES && PERS) ? w4_wait_n(D_, PD, PW, SPREAD, 2 * MT, MT) : WNE_;                    \
+    constexpr int NV_ = w4_pieces(D_, PW, SPREAD), KV_ = (NV_ + MT - 1) / MT;                                  \
+    constexpr int NRL_ = (RES && PERS) ? w4_res_loads(D_, MT) : 0, KRL_ = (NRL_ + MT - 1) / MT;                \
+    const bool lastb_ = hc + 2 >= nhc;                                                                         \
     const int next_b_ = slot_b + DT_B >= NBD * DT_B ? 0 : slot_b + DT_B;                                       \
     int wof_ = wbase + slot_b, wofn_ = wbase + next_b_;                                                        \
     asm volatile("" : "+v"(wof_), "+v"(wofn_));                                                                \
-    W4_SUB(0, 1, wof_ + TILE_B, U1_ / 9, U1_ % 9, 0, 0, W4_NODMA);                                             \
-    /* PERS, first body behind a tile boundary: the 2 MT stores of the epilogue are younger than the double tiles issued before the \
-       boundary (D + 1 - PD < 0) and may stay in flight with them */                                           \
+    W4_SUB(0, 1, wof_ + TILE_B, U1_ / 9, U1_ % 9, NRL_, KRL_, W4_RES_PIECE, 0);                                \
     W4_DSTAMP(2 * (D));                                                                                        \
-    if (PERS && (D) <= PD - 2 && after_epi) W4_WAIT_VM(WN_ + 2 * MT); else W4_WAIT_VM(WN_);                    \
+    if (WNE_ != WN_ && after_epi) { if (WNER_ != WNE_ && lastb_) W4_WAIT_VM(WNER_); else W4_WAIT_VM(WNE_); }   \
+    else if (WNR_ != WN_ && lastb_) W4_WAIT_VM(WNR_);                                                          \
+    else W4_WAIT_VM(WN_);                                                                                      \
     W4_BARRIER();                                                                                              \
     W4_DSTAMP(2 * (D) + 1);                                                                                    \
     int iss_b_ = slot_b + PD * DT_B; if (iss_b_ >= NBD * DT_B) iss_b_ -= NBD * DT_B;                           \
-    const bool lastb_ = hc + 2 >= nhc;                                                                         \
     const int di_ = dn < ND ? dn : dn - ND;                                                                    \
-    if (RES && lastb_ && ((D) == 7 || (D) == 8)) res_slot[RS_] = iss_b_;                                       \
+    if (RES && !PERS && lastb_ && ((D) == 7 || (D) == 8)) res_slot[RS_] = iss_b_;                              \
     ++dn;                                                                                                      \
-    W4_SUB(1, 0, wofn_, U2_ / 9, U2_ % 9, NV_, KV_, W4_DMA_PIECE);                                             \
+    W4_SUB(1, 0, wofn_, U2_ / 9, U2_ % 9, NV_, KV_, W4_DMA_PIECE, 1);                                          \
     slot_b = next_b_;                                                                                          \
   } while (0)
 
@@ -428,13 +479,10 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   const unsigned long long st_l0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_l1 = 0, st_r1 = 0;
 #endif
+  char* const lscr = smem + SCR_B + wave * 3200;           // the epilogue's line image of one pixel tile (2 KB, wave-private)
   for (;;) {
-  bool has_next = false;
-  int n_m0 = 0, n_mend = 0, n_R0 = 0;
-  if constexpr (PERS) {
-    has_next = mt + G_mt < p.mtiles;
-    if (has_next) W4_GEOM(mt + G_mt, n_m0, n_mend, n_R0, n_patch_src); else n_patch_src = patch_src;
-  }
+  const bool has_next = PERS && mt + G_mt < p.mtiles;
+  if constexpr (PERS) n_patch_src = has_next ? patch_src + d_patch : patch_src;
   for (int hcp = 0; hcp < nbody; ++hcp) {
     W4_DSTEP(0); W4_DSTEP(1); W4_DSTEP(2); W4_DSTEP(3); W4_DSTEP(4); W4_DSTEP(5); W4_DSTEP(6); W4_DSTEP(7); W4_DSTEP(8);
     hc += 2;
@@ -446,8 +494,15 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   else if (st_b[5] == 0) st_b[5] = __builtin_amdgcn_s_memtime();      // end of the SECOND tile's loop
 #endif
   W4_BSTAMP(0);
-  // ---- epilogue: (+ residual) (ReLU) -> 16-bit padded NHWC straight from the accumulators
+  // ---- epilogue: (+ residual) (ReLU) -> 16-bit padded NHWC.  A lane's accumulators are one pixel x two runs of 8 channels (MFMA
+  // order); the packed words go through the wave's 2 KB line image and leave as whole 128-byte lines (header).  The image is
+  // wave-private and the LDS operations of a wave execute in order: no barrier.
   if constexpr (!PERS) W4_WAIT_VM(0);                      // look-ahead DMAs (and the residual rounds) have landed
+  else if constexpr (RES) W4_WAIT_VM(w4_pieces(8, PW, SPREAD));   // the residual loads have; the pieces of double step 8 stay in flight
+  if constexpr (RES && PERS) {
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) asm volatile("" : "+a"(rq[pt][0]), "+a"(rq[pt][1]));   // no read of them is scheduled above the wait
+  }
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) {
     float v[NT * 4];
@@ -456,61 +511,75 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
     if constexpr (RES) {
-      {                                                    // this lane's own DMA pieces (no other wave reads them)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < 2; ++c) {
+        u32x4 rv;
+        if constexpr (PERS) rv = rq[PERS ? pt : 0][c];
+        else {                                             // this lane's own DMA pieces (no other wave reads them)
           const int off_ = pt < 4 ? ((pt * 2 + c) * 256 + wave * 64 + lane) * 16
                                   : 2 * PATCH_B + res_slot[(pt - 4) >> 1] + (((pt - 4) & 1) * 2 + c) * 4096 + wave * 1024 + lane * 16;
-          const u32x4 rv = *(const u32x4*)(smem + off_);
+          rv = *(const u32x4*)(smem + off_);
+        }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v[c * 8 + q * 2] += unpack_lo<T>(rv[q]);
-            v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[q]);
-          }
+        for (int q = 0; q < 4; ++q) {
+          v[c * 8 + q * 2] += unpack_lo<T>(rv[q]);
+          v[c * 8 + q * 2 + 1] += unpack_hi<T>(rv[q]);
         }
       }
     }
-    if (ok[pt]) {
-      char* op = (char*)p.out + ooff[pt];
+    u32x4 o[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        u32x4 o;
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = pk_out16<T>(pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]), p.relu);
-        *(u32x4*)(op + c * 64) = o;
-      }
+      for (int q = 0; q < 4; ++q) o[c][q] = pk_out16<T>(pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]), p.relu);
+#ifndef FLOPE_W4_MFMA_STORES
+#pragma unroll
+    for (int c = 0; c < 2; ++c) *(u32x4*)(lscr + r16 * 128 + (((c * 4 + g) ^ (r16 & 7)) << 4)) = o[c];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int pp = c * 8 + (lane >> 3);
+      o[c] = *(const u32x4*)(lscr + pp * 128 + (((lane & 7) ^ (pp & 7)) << 4));
     }
+#endif
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (okl[pt][c]) *(u32x4*)((char*)p.out + osto[pt][c]) = o[c];
   }
   W4_BSTAMP(1);
   if (!has_next) break;
-  // ---- PERS: next tile of this workgroup.  Its first half-chunk (burst of double step 5 of the last body) and its first double
-  // tiles are in LDS or in flight; what is younger than that burst in this wave's queue: the double tiles of double steps 6, 7, 8
-  // and the 2 MT stores just issued (a ragged tile stores fewer: drain, the static counts stay valid)
+  // ---- PERS: next tile of this workgroup's class walk.  Its first half-chunk (burst of double step 5 of the last body), its first
+  // double tiles and -- same table -- the fragments of its first sub-step are in LDS, in flight or in registers; the boundary is
+  // pointer bumps and the accumulators.  What is younger than that burst in this wave's queue: the double tiles of double steps
+  // 6, 7, 8 and the 2 MT stores just issued (w4_after_epi_extra in the first waits of the next body).
   {
-    const bool full = mend - m0 == BM;
-    mt += G_mt; m0 = n_m0; mend = n_mend; R0 = n_R0; patch_src = n_patch_src;
-    if (full) W4_WAIT_VM(3 * TGW + 2 * MT); else W4_WAIT_VM(0);
+    mt += G_mt; patch_src = n_patch_src;
+#pragma unroll
+    for (int pt = 0; pt < MT; ++pt) { osto[pt][0] += d_out; osto[pt][1] += d_out; }
+    if constexpr (RES) {
+#pragma unroll
+      for (int pt = 0; pt < MT; ++pt) ooff[pt] += d_out;
+    }
     W4_BSTAMP(2);
-    W4_TABLE();                                            // (its barrier also publishes the patch)
+    W4_ACC_INIT();
     W4_BSTAMP(3);
-#pragma unroll
-    for (int pt = 0; pt < MT; ++pt)
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
-    after_epi = full;
+    after_epi = true;
+    dn -= ND;
+    hc = 0;
     if constexpr (DSF) {
-      W4_DS_SOURCES();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dsrc[rr] += d_ds;
+      W4_BARRIER();                                        // every wave is done with patch buffer 1 (the last body's second half-chunk)
       W4_DS_CHAIN(false);
       after_epi = false;                                   // the chain's vmcnt(0) drained the queue
     }
-    dn -= ND;
-    hc = 0;
-    int wof0_ = wbase + slot_b;
-    asm volatile("" : "+v"(wof0_));
+    if constexpr (DSF || RES) {                            // the chain used the fragment registers; RES: not carried across the epilogue (registers)
+      int wof0_ = wbase + slot_b;
+      asm volatile("" : "+v"(wof0_));
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) wf[0][ct] = *(const frag*)(smem + wof0_ + ct * 1024);
+      for (int ct = 0; ct < NT; ++ct) wf[0][ct] = *(const frag*)(smem + wof0_ + ct * 1024);
 #pragma unroll
-    for (int pt = 0; pt < MT; ++pt) xf[0][pt] = *(const frag*)(smem + xoff[0][pt]);
+      for (int pt = 0; pt < MT; ++pt) xf[0][pt] = *(const frag*)(smem + xoff[0][pt]);
+    }
     W4_BSTAMP(4);
 #ifdef FLOPE_STAG_DBG
     ++st_tile;
@@ -530,21 +599,20 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     b_[6] = st_l1;
   }
   if ((p.dbg & 64) && p.split_ws && wave == 0 && lane < 18) ((unsigned*)((char*)p.split_ws + 196608))[(size_t)blockIdx.x * 32 + lane] = st_v;
+  if ((p.dbg & 512) && p.split_ws && wave == 0 && lane < 16) ((unsigned*)((char*)p.split_ws + 327680))[(size_t)blockIdx.x * 16 + lane] = st_w;
 #endif
 #undef W4_PSTAMP
 #undef W4_BSTAMP
 #undef W4_DSTAMP
-#undef W4_GEOM
-#undef W4_TABLE
-#undef W4_DS_SOURCES
+#undef W4_GSTAMP
+#undef W4_ACC_INIT
 #undef W4_DS_CHAIN
 #undef W4_DSTEP
 #undef W4_ISSUE_DS
 #undef W4_DMA_PIECE
+#undef W4_RES_PIECE
 #undef W4_ABL_W
 #undef W4_ABL_P
-#undef W4_NODMA
-#undef W4_G0
 #undef W4_VMEM_GROUP
 #undef W4_SUB
 #undef W4_GRP
@@ -552,119 +620,73 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #undef W4_ISSUE_PATCH
 #undef W4_BARRIER
 #undef W4_WAIT_VM
+#undef W4_WAIT_PIN
 }
 
-// own_ds_slot: persistent workgroups with a folded shortcut
-static constexpr size_t w4_lds_bytes(int pt, int nbd, bool own_ds_slot) { return (size_t)2 * pt * 8192 + (size_t)(nbd + (own_ds_slot ? 1 : 0)) * 16384 + 12800; }
+static constexpr size_t w4_lds_bytes(int pt, bool own_ds_slot) {
+  return (size_t)2 * pt * 8192 + (size_t)(w4_ring(pt, own_ds_slot) + (own_ds_slot ? 1 : 0)) * 16384 + 12800;
+}
 
-template <typename T, bool RES, bool DSF, int NBD, bool PERS, int MT>
-static hipError_t w4_attr_pt() {
-  hipError_t e = hipSuccess;
-#define A(PT_) if (e == hipSuccess && w4_lds_bytes(PT_, NBD, DSF && PERS) <= 160 * 1024) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES, DSF, NBD, PERS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A(4) A(5) A(6)
-#undef A
-  return e;
-}
-template <typename T, int NBD>
-static hipError_t w4_attr_n() {       // (224-pixel tiles: one tile per workgroup only)
-  hipError_t e = w4_attr_pt<T, false, false, NBD, false, 8>();
-  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD, false, 8>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false, 8>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, false, NBD, true, 8>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, true, 8>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, false, NBD, false, 7>();
-  if (e == hipSuccess) e = w4_attr_pt<T, true, false, NBD, false, 7>();
-  if (e == hipSuccess) e = w4_attr_pt<T, false, true, NBD, false, 7>();
-  return e;
-}
-// 4..6 pixel tiles per wave: 4 patch rounds, the 5-deep ring only
-template <typename T, int MT>
-static hipError_t w4_attr_small() {
-  hipError_t e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, 4, false, false, 5, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, 4, true, false, 5, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, 4, false, true, 5, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return e;
-}
-template <typename T, int MT>
-static void w4_go_small(const ConvP& p, int grid_blocks, size_t lds, hipStream_t st) {
-  const dim3 grid(grid_blocks), block(256);
-  if (p.ds_in) hipLaunchKernelGGL((conv_w4_kernel<T, 4, false, true, 5, false, MT>), grid, block, lds, st, p);
-  else if (p.res) hipLaunchKernelGGL((conv_w4_kernel<T, 4, true, false, 5, false, MT>), grid, block, lds, st, p);
-  else hipLaunchKernelGGL((conv_w4_kernel<T, 4, false, false, 5, false, MT>), grid, block, lds, st, p);
-}
-template <typename T>
-static hipError_t w4_attr() {
-  hipError_t e = w4_attr_n<T, 3>();
-  if (e == hipSuccess) e = w4_attr_n<T, 4>();
-  if (e == hipSuccess) e = w4_attr_n<T, 5>();
-  if (e == hipSuccess) e = w4_attr_small<T, 4>();
-  if (e == hipSuccess) e = w4_attr_small<T, 5>();
-  if (e == hipSuccess) e = w4_attr_small<T, 6>();
-  return e;
-}
+// instantiated variants: one tile per workgroup at MT = 8, 7 (PT = 4, 5, 6) and MT = 6, 5, 4 (PT = 4); the class walk at MT = 7
+// (PT = 4, 5; with a folded shortcut the 6-round patch leaves no room for the shortcut's own weight slot)
+#define W4_FOR_VARIANTS(X, T)                                                                                  \
+  X(T, 4, false, false, false, 8) X(T, 4, true, false, false, 8) X(T, 4, false, true, false, 8)                \
+  X(T, 5, false, false, false, 8) X(T, 5, true, false, false, 8) X(T, 5, false, true, false, 8)                \
+  X(T, 6, false, false, false, 8) X(T, 6, true, false, false, 8) X(T, 6, false, true, false, 8)                \
+  X(T, 4, false, false, false, 7) X(T, 4, true, false, false, 7) X(T, 4, false, true, false, 7)                \
+  X(T, 5, false, false, false, 7) X(T, 5, true, false, false, 7) X(T, 5, false, true, false, 7)                \
+  X(T, 6, false, false, false, 7) X(T, 6, true, false, false, 7) X(T, 6, false, true, false, 7)                \
+  X(T, 4, false, false, false, 6) X(T, 4, true, false, false, 6) X(T, 4, false, true, false, 6)                \
+  X(T, 4, false, false, false, 5) X(T, 4, true, false, false, 5) X(T, 4, false, true, false, 5)                \
+  X(T, 4, false, false, false, 4) X(T, 4, true, false, false, 4) X(T, 4, false, true, false, 4)                \
+  X(T, 4, false, false, true, 7) X(T, 4, true, false, true, 7) X(T, 4, false, true, true, 7)                   \
+  X(T, 5, false, false, true, 7) X(T, 5, true, false, true, 7) X(T, 5, false, true, true, 7)
 
 extern "C" int flope_conv_w4_init() {
-  hipError_t e = w4_attr<bf16_t>();
-  if (e == hipSuccess) e = w4_attr<f16_t>();
+  hipError_t e = hipSuccess;
+#define A(T, PT_, RES_, DSF_, PERS_, MT_)                                                                      \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_w4_kernel<T, PT_, RES_, DSF_, PERS_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  W4_FOR_VARIANTS(A, bf16_t)
+  W4_FOR_VARIANTS(A, f16_t)
+#undef A
   return (int)e;
 }
 
-template <typename T, bool RES, bool DSF, int NBD, bool PERS, int MT>
-static void w4_go(const ConvP& p, int pt, int grid_blocks, size_t lds, hipStream_t st) {
-  const dim3 grid(grid_blocks), block(256);
-  switch (pt) {
-    case 4: hipLaunchKernelGGL((conv_w4_kernel<T, 4, RES, DSF, NBD, PERS, MT>), grid, block, lds, st, p); break;
-    case 5: hipLaunchKernelGGL((conv_w4_kernel<T, 5, RES, DSF, NBD, PERS, MT>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((conv_w4_kernel<T, 6, RES, DSF, NBD, PERS, MT>), grid, block, lds, st, p); break;
-  }
+// lds bytes of a variant: 2 patch buffers, the weight ring (+ 1 double tile for a persistent workgroup's folded shortcut), 12.5 KB in
+// which the lanes trade their shares of the address table and the epilogue builds its line image; 0 = not instantiated
+extern "C" size_t flope_conv_w4_lds(int pt, int mt, int dsf, int pers) {
+  if (pt < 4 || pt > 6 || mt < 4 || mt > 8 || (mt < 7 && pt != 4) || (pers && (mt != 7 || pt > 5))) return 0;
+  return w4_lds_bytes(pt, dsf && pers);
 }
-template <typename T, int NBD>
-static void w4_go_n(const ConvP& p, int pt, int grid_blocks, int mt, size_t lds, hipStream_t st) {
-  const bool pers = grid_blocks < p.total_tiles;
-  if (mt == 7) {
-    if (p.ds_in) w4_go<T, false, true, NBD, false, 7>(p, pt, grid_blocks, lds, st);
-    else if (p.res) w4_go<T, true, false, NBD, false, 7>(p, pt, grid_blocks, lds, st);
-    else w4_go<T, false, false, NBD, false, 7>(p, pt, grid_blocks, lds, st);
-  } else if (p.ds_in) { if (pers) w4_go<T, false, true, NBD, true, 8>(p, pt, grid_blocks, lds, st); else w4_go<T, false, true, NBD, false, 8>(p, pt, grid_blocks, lds, st); }
-  else if (p.res) w4_go<T, true, false, NBD, false, 8>(p, pt, grid_blocks, lds, st);
-  else { if (pers) w4_go<T, false, false, NBD, true, 8>(p, pt, grid_blocks, lds, st); else w4_go<T, false, false, NBD, false, 8>(p, pt, grid_blocks, lds, st); }
-}
-
-// lds bytes needed: 2 patch buffers, nbd double tiles of weights (+ 1 for the folded shortcut's), 12 KB in which the lanes trade
-// their shares of the address table
-extern "C" size_t flope_conv_w4_lds(int pt, int nbd, int dsf_persistent) { return w4_lds_bytes(pt, nbd, dsf_persistent != 0); }
 
 // 3x3 stride-1 pad-1, Cin % 64 == 0, Cout % 128 == 0, the skewed patch image (p->skew, p->mg_pitch / sh_pitch):
-// mt = 8 .. 4 pixel tiles per wave = 256 .. 128-pixel workgroup tiles (below 7: pt = 4 and nbd = 5 only); p->patch_rows_max = PT (4, 5 or 6: the patch of such a tile),
-// p->mtiles = ceil(M / (32 mt)), p->total_tiles = mtiles * Cout / 128, p->w the conv_stag weight
-// image.  nbd = 3..5 double tiles in the weight ring (the DMA runs nbd - 1 double steps ahead).  grid_blocks = total_tiles: one
-// tile per workgroup; fewer (a multiple of Cout / 128, no residual input, mt = 8): persistent workgroups walk the M tiles.
-extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, int mt, void* stream) {
+// mt = 8 .. 4 pixel tiles per wave = 256 .. 128-pixel workgroup tiles (below 7: pt = 4 only); p->patch_rows_max = PT (4, 5 or 6: the
+// patch of such a tile), p->mtiles = ceil(M / (32 mt)), p->total_tiles = mtiles * Cout / 128, p->w the conv_stag weight image.
+// grid_blocks = total_tiles: one tile per workgroup.  Fewer = the class walk (mt = 7, pt <= 5): grid_blocks = G * Cout / 128 where G
+// divides mtiles, M % 224 == 0 and G tiles are p->cw_imgs whole images (G * 224 == cw_imgs * Ho * Wo).
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int grid_blocks, int mt, void* stream) {
   const int pt = p->patch_rows_max;
-  if (mt < 4 || mt > 8 || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || (mt < 8 && grid_blocks != p->total_tiles) ||
-      (mt < 7 && (pt != 4 || nbd != 5)) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 || !p->skew || !p->mg_pitch || p->ksplit > 1 || nbd < 3 || nbd > 5 ||
-      (pt != 4 && pt != 5 && pt != 6) || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)) ||
-      grid_blocks < p->ntiles || grid_blocks > p->total_tiles || grid_blocks % p->ntiles || (p->res && grid_blocks != p->total_tiles) ||
-      p->total_tiles != p->mtiles * p->ntiles)
+  const bool pers = grid_blocks < p->total_tiles;
+  if (mt < 4 || mt > 8 || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 ||
+      !p->skew || !p->mg_pitch || p->ksplit > 1 || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)) ||
+      grid_blocks < p->ntiles || grid_blocks > p->total_tiles || grid_blocks % p->ntiles || p->total_tiles != p->mtiles * p->ntiles)
     return (int)hipErrorInvalidValue;
-  const size_t lds = w4_lds_bytes(pt, nbd, p->ds_in != nullptr && grid_blocks < p->total_tiles);
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-#define GO(T)                                                                                                  \
-  do {                                                                                                         \
-    switch (nbd) {                                                                                             \
-      case 3: w4_go_n<T, 3>(*p, pt, grid_blocks, mt, lds, st); break;                                          \
-      case 4: w4_go_n<T, 4>(*p, pt, grid_blocks, mt, lds, st); break;                                          \
-      default: w4_go_n<T, 5>(*p, pt, grid_blocks, mt, lds, st); break;                                         \
-    }                                                                                                          \
-  } while (0)
-  if (mt < 7) {
-#define GS(T) do { if (mt == 4) w4_go_small<T, 4>(*p, grid_blocks, lds, st); else if (mt == 5) w4_go_small<T, 5>(*p, grid_blocks, lds, st); else w4_go_small<T, 6>(*p, grid_blocks, lds, st); } while (0)
-    if (dtype == 0) GS(bf16_t); else GS(f16_t);
-#undef GS
-    return (int)hipGetLastError();
+  if (pers) {
+    const int G = grid_blocks / p->ntiles;
+    if (mt != 7 || p->M % 224 || p->mtiles % G || p->cw_imgs < 1 || (long)G * 224 != (long)p->cw_imgs * p->Ho * p->Wo) return (int)hipErrorInvalidValue;
   }
-  if (dtype == 0) GO(bf16_t); else GO(f16_t);
-#undef GO
+  const size_t lds = flope_conv_w4_lds(pt, mt, p->ds_in != nullptr, pers);
+  if (lds == 0 || lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(grid_blocks), block(256);
+  const int res = p->res ? 1 : 0, dsf = p->ds_in ? 1 : 0;
+  bool done = false;
+#define L(T, PT_, RES_, DSF_, PERS_, MT_)                                                                      \
+  if (!done && pt == PT_ && res == (RES_ ? 1 : 0) && dsf == (DSF_ ? 1 : 0) && pers == PERS_ && mt == MT_) {     \
+    hipLaunchKernelGGL((conv_w4_kernel<T, PT_, RES_, DSF_, PERS_, MT_>), grid, block, lds, st, *p); done = true; \
+  }
+  if (dtype == 0) { W4_FOR_VARIANTS(L, bf16_t) } else { W4_FOR_VARIANTS(L, f16_t) }
+#undef L
+  if (!done) return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
 }

@@ -27,7 +27,6 @@ extern "C" int flope_avgpool_launch(const void* in, float* out, int B, int h, in
 extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* W1p, const float* b1, float* hidden, int B, int K, int N, void* stream);
 extern "C" int flope_fc2_procrustes_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, const float* xyz, int nullify, float* Rt, void* stream);
 extern "C" int flope_fc2_procrustes_k4_launch(const float* hidden, const float* W2, const float* b2, float* r9, float* R, int B, int K, const float* xyz, int nullify, float* Rt, void* stream);
-extern "C" int flope_avgpool_fc1_launch(const void* in, const float* W1p, const float* b1, float* feat, float* hidden, int B, int h, int w, int C, int N, int dtype, void* stream);
 extern "C" int flope_prep_input_launch(const void* x, int in_format, int B, int H, int W, void* out, int Hip, int Wip, int dtype, void* stream);
 extern "C" int flope_read_stage_launch(const void* in, float* out, int B, int C, int h, int w, int dtype, void* stream);
 extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream);
@@ -37,8 +36,8 @@ extern "C" int flope_conv_w4_init();
 extern "C" int flope_conv_r4_init();
 extern "C" int flope_conv_r4_ok(const ConvP* p);
 extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream);
-extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int nbd, int grid_blocks, int mt, void* stream);
-extern "C" size_t flope_conv_w4_lds(int pt, int nbd, int dsf);
+extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int grid_blocks, int mt, void* stream);
+extern "C" size_t flope_conv_w4_lds(int pt, int mt, int dsf, int pers);
 extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
@@ -47,7 +46,7 @@ extern "C" int flope_stem_pool_init();
 extern "C" void flope_stem_pool_set_dbg(void* ptr);
 #endif
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
-                                      const void* w, const float* bias, void* out, int dtype, int persist_blocks, int regpool, void* stream);
+                                      const void* w, const float* bias, void* out, int dtype, int persist_blocks, void* stream);
 
 using namespace flope_host;
 
@@ -82,6 +81,8 @@ struct Conv {
   int folded = 0, ds_conv = -1;
   void* w_ds_stag = nullptr;   // downsample conv only: its weights as a conv_stag image
   float* bias_fused = nullptr; // conv2 only
+  // what the LAST forward launched for this conv (run_slice): kernel family as flope_launch_info names it, and the launch's shape
+  mutable std::string last_kernel, last_detail;
 };
 
 struct Buf { void* ptr = nullptr; size_t bytes = 0; int C = 0, h = 0, w = 0; };
@@ -103,7 +104,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_stem_regpool = 0, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4p = 0, opt_w4grid = 0, opt_head_fuse = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 5;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 3..6 = conv_w4 (4 waves) with a weight ring of up to that many double tiles
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -517,7 +518,7 @@ extern "C" int flope_destroy(flope_handle e) {
 }
 
 // developer aid (diagnostic builds, -DFLOPE_STAG_DBG + option dbg = 64): copies `bytes` of the split-K workspace, where conv launch i
-// of the last forward left its clock stamps at byte offset i * 131072, to host memory
+// of the last forward left its clock stamps at byte offset i * 1 MiB (kDbgRegion), to host memory
 extern "C" int flope_debug_read_ws(flope_handle e, void* dst_host, size_t offset, size_t bytes) {
   if (!e || !dst_host) return fail(e, FLOPE_EINVAL, "flope_debug_read_ws: NULL argument");
   if (!e->split_ws || offset + bytes > e->split_ws_bytes) return fail(e, FLOPE_EINVAL, "flope_debug_read_ws: out of range");
@@ -539,17 +540,15 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "w4mtlo")) { prev = e->opt_w4mtlo; e->opt_w4mtlo = value <= 0 ? 0 : (value < 4 ? 4 : (value > 8 ? 8 : value)); return prev; }   // smallest tile height the per-launch choice may take (0: 7 with two slices in flight, 5 alone)
   else if (!strcmp(name, "lag")) { prev = e->opt_lag; e->opt_lag = value < 0 ? 0 : (value > 500 ? 500 : value); return prev; }   // microseconds by which the last batch slice starts late (default 20; 0 = off)
   else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value >= 4 && value <= 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 4..8 = 128..256 pixels (where the shape has that instantiation)
-  else if (!strcmp(name, "head_fuse")) { prev = e->opt_head_fuse; e->opt_head_fuse = value != 0; return prev; }   // avgpool + fc.0 in one launch (bit-identical to the two)
   else if (!strcmp(name, "fc2_k4")) { prev = e->opt_fc2_k4; e->opt_fc2_k4 = value != 0; return prev; }            // fc_rot: K split over the four waves of a workgroup per image
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
-  else if (!strcmp(name, "stem_regpool")) { prev = e->opt_stem_regpool; e->opt_stem_regpool = value != 0; return prev; }
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
-  else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = (value >= 3 && value <= 6) ? value : 0; return prev; }
-  else if (!strcmp(name, "w4grid")) { prev = e->opt_w4grid; e->opt_w4grid = value < 0 ? 0 : value; return prev; }
-  else if (!strcmp(name, "w4p")) { prev = e->opt_w4p; e->opt_w4p = value != 0; return prev; }
+  else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = value != 0; return prev; }
+  else if (!strcmp(name, "w4cw")) { prev = e->opt_w4cw; e->opt_w4cw = value < 0 ? 0 : (value > 64 ? 64 : value); return prev; }   // conv_w4 class walk: tiles per persistent workgroup aimed at (0 / 1 = one tile per workgroup)
+  else if (!strcmp(name, "w4cwf")) { prev = e->opt_w4cwf; e->opt_w4cwf = value & 3; return prev; }   // ... bit 0: also with several batch slices in flight, bit 1: also where the walk fills < 85 % of the slice's CUs
   else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "reslds")) { prev = e->opt_reslds; e->opt_reslds = value != 0; return prev; }
   else if (!strcmp(name, "gstag")) { prev = e->opt_gstag; e->opt_gstag = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -638,13 +637,6 @@ static bool w4_eligible(const flope_engine* e, const Conv& c) {
   return e->opt_w4 && !e->opt_persist && c.stag == 1 && c.cout >= 128 && e->opt_skew && c.stag_patch_bytes >= 4 && c.stag_patch_bytes <= 6;
 }
 
-// avgpool + fc.0 as one launch (pool_head.hip avgpool_fc1_kernel): 16-bit trunk, packed W1, 256 | backbone_out_dim, final map <= 64 px
-static bool head_fused(const flope_engine* e) {
-  if (!e->opt_head_fuse || !e->opt_fc1_packed || e->dtype == FLOPE_DT_F32 || !e->W1p || e->bod % 256 || e->final_buf < 0) return false;
-  const Buf& b = e->bufs[e->final_buf];
-  return b.h * b.w <= 64;
-}
-
 struct PoseOut { const float* xyz = nullptr; int nullify = 0; float* Rt = nullptr; };   // optional [B,16] pose assembly
 
 static int run_slice(flope_engine* e, const void* x_dev, int in_format, int start, int batch, void* stream, bool marks,
@@ -670,11 +662,8 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
                                                    e->stem_bias, bp.ptr, dt,
                                                    // persistent form where it measured faster (r02, same-run A/B at B = 256): 224 x 224 crops
                                                    // +2.7 % on the step; 512 x 512 crops -7 % on the kernel.  1 = auto, 2 = always, 0 = never
-                                                   // stem_regpool (r02, off): the register-pool kernel, three workgroups per CU -- measured slower
-                                                   // (197 vs 150 us at 224 x 224, 983 vs 697 us at 512 x 512: +30 % MFMAs for the duplicated rows)
-                                                   e->opt_stem_regpool ? 3 * e->num_cus
-                                                   : (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
-                                                   e->opt_stem_regpool, stream));
+                                                   (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
+                                                   stream));
   } else {
     SMARK();
     K_TRY(e, "prep_input", flope_prep_input_launch(x, in_format, batch, e->H, e->W, stem_in, e->sHip, e->sWip, dt, stream));
@@ -713,6 +702,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       ConvP p; conv_params(e, vb, c, batch, &p);
       p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + 255) / 256; p.ntiles = c.cout / 128; p.total_tiles = p.mtiles * p.ntiles;
       SMARK();
+      c.last_kernel = "conv_gstag_kernel<256x128,s2>"; c.last_detail.clear();
       K_TRY(e, c.name.c_str(), flope_conv_gstag_launch(&p, dt, stream));
     } else if (c.stag) {
       ConvP p; conv_params(e, vb, c, batch, &p);
@@ -744,6 +734,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
         if ((e->opt_dbg & 64) && e->split_ws) p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
         SMARK();
+        c.last_kernel = "conv_r4_kernel<8rows x56>"; c.last_detail.clear();
         K_TRY(e, c.name.c_str(), flope_conv_r4_launch(&p, dt, gridb, stream));
         continue;
       }
@@ -772,22 +763,13 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       p.res_lds = (e->opt_reslds && p.res && c.stag == 1 && c.cout >= 128 && c.stag_patch_bytes >= 4 && ksp == 1 && gridb == p.total_tiles) ? 1 : 0;
       if ((e->opt_dbg & (64 | 128)) && ksp == 1 && e->split_ws)      // diagnostic build: clock stamps of this launch (flope_debug_read_ws)
         p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
-      // r03: flat 256 x 128 tiles, one tile per workgroup, no split-K -> the 4-wave kernel (conv_w4.hip)
+      // r03: flat 256 x 128 tiles, no split-K -> the 4-wave kernel (conv_w4.hip)
       if (w4_eligible(e, c) && ksp == 1 && gridb == p.total_tiles && !(e->opt_dbg & 128)) {
-        // persistent workgroups (w4p; no residual input): this slice's share of the CUs, a multiple of the channel tiles
-        int gw = p.total_tiles;
-        if (e->opt_w4p && !p.res) {
-          gw = std::min(p.total_tiles, e->opt_w4grid > 0 ? e->opt_w4grid   // (tests: a small grid makes every workgroup walk several tiles)
-                                                   : std::max(1, (int)((long)e->num_cus * batch / std::max(1, e->cur_batch))));
-          gw -= gw % p.ntiles;
-          if (gw < p.ntiles) gw = p.ntiles;
-        }
-        const int dsf = (p.ds_in && gw < p.total_tiles) ? 1 : 0;       // a folded shortcut needs its own weight slot only there
         // workgroup tiles of 256 .. 128 pixels (8 .. 4 pixel tiles per wave; one tile per workgroup): the cheapest by whole rounds
         // of the chip x the time of a tile -- ~15 k cycles of prologue + epilogue, and per double step 128 cycles of MFMAs per
         // pixel tile + ~500 of everything else (r03 stamps: 1.52 k at 8, 1.4 k at 7); ties go to the larger tile
         int mt = 8, ptr = c.stag_patch_bytes;
-        if (gw == p.total_tiles && e->opt_w4mt != 8) {
+        if (e->opt_w4mt != 8) {
           const double dsteps = 9.0 * (c.cin / 64 + (p.ds_in ? 1 : 0));
           // Measured (profiles/r03_conv_w4_tile_height_ab.txt): with two batch slices in flight only 224 against 256 pays (+1.8 % on
           // the step; letting the choice go down to 128 or sizing it to the slice's share of the CUs loses 2 - 5 %: the other slice's
@@ -802,44 +784,67 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
           double best = e->opt_w4mt ? 1e30 : cost(8);
           for (int m = 7; m >= mt_lo; --m) {
             if (!c.w4_patch[m] || (e->opt_w4mt && e->opt_w4mt != m)) continue;
-            if (m < 7 && (std::min(e->opt_w4, 5) != 5 || flope_conv_w4_lds(4, 5, 0) > kLdsMax)) continue;
             const double cm = cost(m);
             if (cm < best) { best = cm; mt = m; }
           }
-          if (mt != 8) { ptr = c.w4_patch[mt]; p.mtiles = (p.M + 32 * mt - 1) / (32 * mt); p.total_tiles = p.mtiles * p.ntiles; gw = p.total_tiles; p.patch_rows_max = ptr; }
         }
-        int nbd = std::min(e->opt_w4, 5);                  // weight-ring depth asked for; the deepest that fits the CU's LDS
-        while (nbd > 3 && flope_conv_w4_lds(ptr, nbd, dsf) > kLdsMax) --nbd;
-        if (flope_conv_w4_lds(ptr, nbd, dsf) <= kLdsMax) {
+        // class walk (option w4cw = tiles per workgroup aimed at): 224-pixel tiles, every tile whole, a walk step of G tiles = whole
+        // images (G a multiple of the tiling's period lcm(Ho Wo, 224) / 224), G | mtiles.  The largest k <= w4cw that allows it.
+        int gw = 0, cw_imgs = 0;
+        // Measured at B = 256 (profiles/r04_conv_w4_class_walk_ab.txt): one slice -2.3 % per step (layer 2 at 4 tiles per workgroup
+        // -14 %, layer 3 at 2 tiles -5 %); with two slices in flight +0.5 % -- 896 tiles of 224 pixels are 3.5 per CU, equal walks
+        // leave 32 CUs idle where the one-tile-per-workgroup launches of the two slices fill each other's gaps.  So: where a launch
+        // has the chip to itself (option w4cwf overrides).
+        if (e->opt_w4cw >= 2 && (e->cur_slices == 1 || (e->opt_w4cwf & 1)) && (e->opt_w4mt == 0 || e->opt_w4mt == 7) && c.w4_patch[7] && p.M % 224 == 0 &&
+            flope_conv_w4_lds(c.w4_patch[7], 7, p.ds_in ? 1 : 0, 1) != 0) {
+          const long hw = (long)c.hout * c.wout;
+          long a_ = hw, b_ = 224; while (b_) { const long t_ = a_ % b_; a_ = b_; b_ = t_; }   // gcd
+          const int period = (int)(hw / a_), mt7 = p.M / 224;
+          // ... and that still fills this slice's share of the CUs (a walk of 112 workgroups on 256 CUs loses more than the tile
+          // boundaries it saves: profiles/r04_conv_w4_class_walk_layers.txt)
+          const long share = std::max(1L, (long)e->num_cus * batch / std::max(1, e->cur_batch));
+          for (int k = std::min(e->opt_w4cw, mt7); k >= 2 && !gw; --k)
+            if (mt7 % k == 0 && (mt7 / k) % period == 0 && ((e->opt_w4cwf & 2) || (long)(mt7 / k) * p.ntiles * 100 >= share * 85)) { gw = mt7 / k; cw_imgs = (int)((long)gw * 224 / hw); }
+          if (gw) mt = 7;
+        }
+        if (mt != 8) { ptr = c.w4_patch[mt]; p.mtiles = (p.M + 32 * mt - 1) / (32 * mt); p.total_tiles = p.mtiles * p.ntiles; p.patch_rows_max = ptr; }
+        const int grid_w4 = gw ? gw * p.ntiles : p.total_tiles;
+        p.cw_imgs = gw ? cw_imgs : 0;
+        if (flope_conv_w4_lds(ptr, mt, p.ds_in ? 1 : 0, gw ? 1 : 0) != 0) {
           fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
           SMARK();
-          K_TRY(e, c.name.c_str(), flope_conv_w4_launch(&p, dt, nbd, gw, mt, stream));
+          {
+            char d_[96];
+            if (gw) snprintf(d_, sizeof d_, "[%d px tiles, walk: %d workgroups x %d tiles]", 32 * mt, grid_w4, p.mtiles / gw);
+            else snprintf(d_, sizeof d_, "[%d px tiles]", 32 * mt);
+            c.last_kernel = "conv_w4_kernel<256x128>"; c.last_detail = d_;
+          }
+          K_TRY(e, c.name.c_str(), flope_conv_w4_launch(&p, dt, grid_w4, mt, stream));
           continue;
         }
+        p.cw_imgs = 0;
         if (mt != 8) { p.mtiles = (p.M + 255) / 256; p.total_tiles = p.mtiles * p.ntiles; p.patch_rows_max = c.stag_patch_bytes; }
       }
       size_t lds_bytes = c.stag_lds;
       if ((e->opt_dbg & 128) && lds_bytes + 2048 <= kLdsMax) { p.dbg_lds_off = (int)lds_bytes; lds_bytes += 2048; }
       else if (e->opt_dbg & 128) p.dbg &= ~128;
       SMARK();
+      c.last_kernel = c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>");
+      c.last_detail = ksp > 1 ? "[split-K x" + std::to_string(ksp) + "]" : std::string();
       K_TRY(e, c.name.c_str(), flope_conv_stag_launch(&p, dt, gridb, lds_bytes, stream));
       if (ksp > 1) K_TRY(e, c.name.c_str(), flope_conv_split_finalize_launch(&pf, dt, stream));
     } else {
       ConvP p; conv_params(e, vb, c, batch, &p);
       SMARK();
+      c.last_kernel.clear(); c.last_detail.clear();       // (flope_launch_info derives conv_mfma's label from the static plan)
       K_TRY(e, c.name.c_str(), flope_conv_mfma_launch(&p, dt, c.cfg, c.patch, c.nbuf, c.lds + (size_t)e->opt_ldspad * 1024, stream));
     }
   }
   const Buf& bl = vb[e->final_buf];
   SMARK();
-  if (head_fused(e)) {
-    const int rc = flope_avgpool_fc1_launch(bl.ptr, e->W1p, e->b1, feat, hidden, batch, bl.h, bl.w, 512, e->bod, dt, stream);
-    if (rc != 1) return fail(e, FLOPE_EHIP, "avgpool+fc1: launch failed");
-  } else {
-    K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
-    SMARK();
-    K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->opt_fc1_packed ? e->W1p : nullptr, e->b1, hidden, batch, 512, e->bod, stream));
-  }
+  K_TRY(e, "avgpool", flope_avgpool_launch(bl.ptr, feat, batch, bl.h, bl.w, 512, dt, stream));
+  SMARK();
+  K_TRY(e, "fc1", flope_fc1_launch(feat, e->W1, e->opt_fc1_packed ? e->W1p : nullptr, e->b1, hidden, batch, 512, e->bod, stream));
   if (head) {
     SMARK();
     float* r9 = (r9_dev ? r9_dev : e->r9_scratch) + (size_t)start * 9;
@@ -905,7 +910,11 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
     // the last slice starts ~20 us late (one sleeping wave): the time line (profile = 2) shows the slices walking the same layers
     // side by side, every pair of launches starting in the same microsecond -- i.e. their prologue fills and epilogue drains
     // coincide; a small offset is +0.7 .. +1.4 % on the step (5 .. 30 us all do; 80 us and more lose: profiles/r03_slice_lag.txt)
-    if (e->opt_lag && s == ns - 1) hipLaunchKernelGGL(lag_kernel, dim3(1), dim3(64), 0, e->side[s], e->opt_lag);
+    // (measured at B = 256 x 224 x 224 only: applied from 192 crops up, where a step is >= 35 x the offset)
+    if (e->opt_lag && s == ns - 1 && batch >= 192) {
+      hipLaunchKernelGGL(lag_kernel, dim3(1), dim3(64), 0, e->side[s], e->opt_lag);
+      if (hipGetLastError() != hipSuccess) { rc_all = fail(e, FLOPE_EHIP, "lag kernel launch failed"); break; }
+    }
     rc_all = run_slice(e, x_dev, in_format, start, cnt, e->side[s], e->opt_profile == 2, head, r9_dev, R_dev, po);
   }
   // join every stream that was forked -- also after a failed launch, so that work already queued on the side
@@ -978,7 +987,7 @@ extern "C" double flope_forward_flops(flope_handle e, int batch) {
 }
 
 static int head_launches(const flope_engine* e) { return (e->opt_fuse_stem && e->dtype != FLOPE_DT_F32) ? 1 : 3; }   // front of the trunk: input + stem + maxpool
-static int tail_launches(const flope_engine* e) { return head_fused(e) ? 2 : 3; }                                   // avgpool, fc.0, fc_rot + Procrustes
+static int tail_launches(const flope_engine*) { return 3; }                                                           // avgpool, fc.0, fc_rot + Procrustes
 extern "C" int flope_forward_launches(flope_handle e) {
   if (!e) return 0;
   int n = (int)e->convs.size() + tail_launches(e) + head_launches(e);
@@ -990,7 +999,7 @@ extern "C" int flope_forward_launches(flope_handle e) {
 // events recorded on the caller's stream around every launch.  Synchronises on the last event.
 extern "C" int flope_profile_read(flope_handle e, float* ms_out, int cap) {
   if (!e || !ms_out) return fail(e, FLOPE_EINVAL, "flope_profile_read: NULL argument");
-  if (!e->opt_profile || e->ev_n < 2) return fail(e, FLOPE_ESTATE, "flope_profile_read: no profiled forward (set option \"profile\" first)");
+  if (e->opt_profile != 1 || e->ev_n < 2) return fail(e, FLOPE_ESTATE, "flope_profile_read: no forward with option profile = 1 (profile = 2 records a time line: flope_profile_timeline)");
   HIP_TRY(e, hipEventSynchronize(e->ev[e->ev_n - 1]));
   const int n = std::min(cap, e->ev_n - 1);
   for (int i = 0; i < n; ++i) HIP_TRY(e, hipEventElapsedTime(&ms_out[i], e->ev[i], e->ev[i + 1]));
@@ -1043,16 +1052,18 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     else if (c.stag == 2 && e->opt_r4 && c.nseg <= 1 && c.cin == 64 && c.cout == 64 && c.wout == 56 && c.hout % 8 == 0) snprintf(k, sizeof k, "conv_r4_kernel<8rows x56>");
     else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));
     else snprintf(k, sizeof k, "conv_mfma_kernel<%dx%d,%s,ring%d>", BM, BN, c.patch ? "patch" : "gather", c.nbuf);
-    s = c.name + "|" + k;
+    // a forward has run: the kernel it actually launched (split-K and shapes the 4-wave kernels do not take go to conv_stag at
+    // launch time, whatever the static plan says) and the launch's tiling
+    if (!f32 && e->last_batch > 0 && !c.last_kernel.empty()) snprintf(k, sizeof k, "%s", c.last_kernel.c_str());
+    s = c.name + ((!f32 && e->last_batch > 0) ? c.last_detail : std::string()) + "|" + k;
     f = 2.0 * c.hout * c.wout * c.cout * c.cin * c.k * c.k;
     if (c.ds_conv >= 0) {
       const Conv& cd = e->convs[c.ds_conv];
-      s = c.name + "+shortcut|" + k;
+      s = c.name + "+shortcut" + ((!f32 && e->last_batch > 0) ? c.last_detail : std::string()) + "|" + k;
       f += 2.0 * cd.hout * cd.wout * cd.cout * cd.cin;
     }
-  } else if (head_fused(e) && idx == 3 + nc) { s = "avgpool+fc1|avgpool_fc1_kernel"; f = 2.0 * 512 * e->bod; }
-  else if (!head_fused(e) && idx == 3 + nc) s = "avgpool|avgpool_kernel";
-  else if (!head_fused(e) && idx == 4 + nc) { s = "fc1|fc1_kernel"; f = 2.0 * 512 * e->bod; }
+  } else if (idx == 3 + nc) s = "avgpool|avgpool_kernel";
+  else if (idx == 4 + nc) { s = "fc1|fc1_kernel"; f = 2.0 * 512 * e->bod; }
   else { s = "fc_rot+procrustes|fc2_procrustes_kernel"; f = 2.0 * 9 * e->bod; }
   snprintf(name, name_cap, "%s", s.c_str());
   *flops = f * batch;
@@ -1071,7 +1082,7 @@ extern "C" int flope_describe_plan(flope_handle e, char* buf, int buflen) {
     if (c.folded) { snprintf(line, sizeof line, "%s: 1x1 s2 %d->%d out %dx%d folded into the next conv (conv_stag DSF)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout); s += line; continue; }
     if (c.stag && c.ds_conv >= 0) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d %s 256x128 patch_rounds=%d lds=%zu, shortcut folded in (+%d K)\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, w4_eligible(e, c) ? "conv_w4" : "conv_stag", c.stag_patch_bytes, c.stag_lds, e->convs[c.ds_conv].cin); s += line; continue; }
     if (c.stag == 2 && c.nseg > 1) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x %d column segments of 64 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.nseg, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
-    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, std::max(3, std::min(std::min(e->opt_w4, 5), (int)((kLdsMax - 12800 - 2 * c.stag_patch_bytes * 8192) / 16384))), 0)); s += line; continue; }
+    if (c.stag == 1 && w4_eligible(e, c)) { snprintf(line, sizeof line, "%s: 3x3 s1 %d->%d out %dx%d conv_w4 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, flope_conv_w4_lds(c.stag_patch_bytes, 8, 0, 0)); s += line; continue; }
     if (c.stag) { snprintf(line, sizeof line, c.stag == 2 ? "%s: 3x3 s1 %d->%d out %dx%d conv_stag 8-row bands x 64 patch_rounds=%d lds=%zu\n" : "%s: 3x3 s1 %d->%d out %dx%d conv_stag 256x128 patch_rounds=%d lds=%zu\n", c.name.c_str(), c.cin, c.cout, c.hout, c.wout, c.stag_patch_bytes, c.stag_lds); s += line; continue; }
     snprintf(line, sizeof line, "%s: %dx%d s%d %d->%d out %dx%d cfg=%d patch=%d ring=%d per_image=%d rows=%d lds=%zu\n", c.name.c_str(),
              c.k, c.k, c.stride, c.cin, c.cout, c.hout, c.wout, c.cfg, c.patch, c.nbuf, c.per_image, c.rows_max, c.lds);

@@ -268,142 +268,8 @@ __global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict
   }
 }
 
-// ---------------------------------------------------------------------------
-// avgpool + fc.0 + ReLU in ONE launch (r03; VERDICT r2 item 4: the head was three dependent launches of 8 + 16 + 23 us).
-// MEASURED SLOWER, option "head_fuse", off: 38.9 us against 8.5 + 16.0 for the two launches.  The fusion has to multiply either the
-// pooling reads or the weight reads: fc1_packed streams each 128 KB weight slab to 8 workgroups (32 MB of L2 reads per launch);
-// with 8 images per workgroup (so that the pooling is repeated only 8 times) every slab goes to 32 workgroups (128 MB) and half of
-// each fp32 MFMA's columns are padding.  Kept as the tested record of that experiment.
-// Workgroup = 8 images x 256 outputs (grid N / 256 x ceil(B / 8): 256 workgroups at B = 256, N = 2048):
-//   1. pool its 8 images out of the last conv's padded NHWC map into LDS -- thread = (pixel group pg of 4, 8 channels), 16-byte
-//      loads, the SAME partial sums in the SAME order as avgpool_kernel ((s_pg over i = pg, pg + 4, ...; then
-//      (s_0 + s_1 + s_2 + s_3) / npx), so `feat` is bit-identical to the unfused path; the N / 256 workgroups of an image block
-//      each pool for themselves (8 x 50 KB of L2 reads instead of a launch boundary), block 0 also writes `feat` (stage tap);
-//   2. fc.0 exactly as fc1_packed_kernel computes it (same W1p fragments, same K order, two accumulator chains per output):
-//      wave = 4 output tiles x one image tile whose columns 8..15 are zero -> `hidden` is bit-identical too.
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool_fc1_kernel(const void* __restrict__ in, const float* __restrict__ W1p,
-                                                          const float* __restrict__ b1, float* __restrict__ feat,
-                                                          float* __restrict__ hidden, int B, int h, int w, int N) {
-  constexpr int K = 512, KB = K / 32, pitch = K + 4, IMG = 8;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* const red = sm;                                    // [IMG][4 pg][K]
-  float* const sfeat = sm + IMG * 4 * K;                    // [16][pitch], rows IMG..15 = 0
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, r16 = lane & 15;
-  const int img0 = blockIdx.y * IMG;
-  const int Wp = w + 2, npx = h * w;
-  // weight fragments of the first K blocks go out before the pooling loads (nothing below depends on them for microseconds)
-  constexpr int NU = 4, WPD = 2;
-  const int nt0 = blockIdx.x * 16 + wave * NU;              // this wave's first 16-output tile
-  const f32x4* wp = (const f32x4*)W1p + (size_t)nt0 * KB * 2 * 64 + lane;
-  f32x4 wa[WPD][NU][2];
-#pragma unroll
-  for (int d = 0; d < WPD; ++d)
-#pragma unroll
-    for (int u = 0; u < NU; ++u) { wa[d][u][0] = wp[((size_t)u * KB + d) * 128]; wa[d][u][1] = wp[((size_t)u * KB + d) * 128 + 64]; }
-  {
-    // pooling: pixel group pg = wave, channel octet cq = lane.  All (<= 16) loads of an image are issued before the first add --
-    // with four in flight per thread the 400 KB of a workgroup took 30 us (measured): latency, not bytes
-    const int pg = wave, cq = lane;
-    constexpr int NPX = 16;                                 // npx <= 64 (launcher)
-    int off[NPX];
-#pragma unroll
-    for (int k = 0; k < NPX; ++k) {
-      const int i = min(pg + 4 * k, npx - 1), y = i / w, x = i - y * w;
-      off[k] = ((y + 1) * Wp + x + 1) * (K * 2);
-    }
-    const int cnt = (npx - pg + 3) >> 2;                    // pixels of this group: i = pg, pg + 4, ... < npx
-    for (int j = 0; j < IMG; ++j) {
-      const int img = min(img0 + j, B - 1);
-      const char* base = (const char*)in + (size_t)img * (h + 2) * Wp * (K * 2) + cq * 16;
-      u32x4 v[NPX];
-#pragma unroll
-      for (int k = 0; k < NPX; ++k) v[k] = *(const u32x4*)(base + off[k]);
-      float s[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s[q] = 0.f;
-#pragma unroll
-      for (int k = 0; k < NPX; ++k)
-        if (k < cnt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { s[2 * q] += unpack_lo<T>(v[k][q]); s[2 * q + 1] += unpack_hi<T>(v[k][q]); }
-        }
-      float* r = red + (j * 4 + pg) * K + cq * 8;
-      *(f32x4*)r = f32x4{s[0], s[1], s[2], s[3]};
-      *(f32x4*)(r + 4) = f32x4{s[4], s[5], s[6], s[7]};
-    }
-  }
-  __syncthreads();
-  {
-    const float inv = 1.f / (float)npx;
-    for (int i = tid; i < 16 * K; i += 256) {
-      const int j = i / K, c = i - j * K;
-      float f = 0.f;
-      if (j < IMG) {
-        const float* r = red + j * 4 * K + c;
-        f = (r[0] + r[K] + r[2 * K] + r[3 * K]) * inv;
-        if (blockIdx.x == 0 && img0 + j < B) feat[(size_t)(img0 + j) * K + c] = f;
-      }
-      sfeat[j * pitch + c] = f;
-    }
-  }
-  __syncthreads();
-  f32x4 acc[NU][2];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) { acc[u][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][1] = acc[u][0]; }
-  const float* f0p = sfeat + r16 * pitch + 4 * g;
-  for (int kb0 = 0; kb0 < KB; kb0 += WPD) {
-#pragma unroll
-    for (int d = 0; d < WPD; ++d) {
-      const int kb = kb0 + d;
-      f32x4 a0[NU], a1[NU];
-      const int nb = min(kb + WPD, KB - 1);
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        a0[u] = wa[d][u][0]; a1[u] = wa[d][u][1];
-        wa[d][u][0] = wp[((size_t)u * KB + nb) * 128]; wa[d][u][1] = wp[((size_t)u * KB + nb) * 128 + 64];
-      }
-      const f32x4 f0 = *(const f32x4*)(f0p + kb * 32), f1 = *(const f32x4*)(f0p + kb * 32 + 16);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][s], f0[s], acc[u][0], 0, 0, 0);
-          acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][s], f1[s], acc[u][1], 0, 0, 0);
-        }
-    }
-  }
-  const int img = img0 + r16;
-  if (r16 < IMG && img < B) {
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int n0 = (nt0 + u) * 16;
-      const f32x4 bias = *(const f32x4*)(b1 + n0 + 4 * g);
-      f32x4 o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = fmaxf(acc[u][0][q] + acc[u][1][q] + bias[q], 0.f);
-      *(f32x4*)(hidden + (size_t)img * N + n0 + 4 * g) = o;
-    }
-  }
-}
-
-// 1 = launched; 0 = shape not covered (the caller runs avgpool + fc1)
-extern "C" int flope_avgpool_fc1_launch(const void* in, const float* W1p, const float* b1, float* feat, float* hidden, int B,
-                                        int h, int w, int C, int N, int dtype, void* stream) {
-  if (!W1p || C != 512 || N % 256 || h * w > 64 || dtype > 1 || B < 1) return 0;
-  const size_t lds = (size_t)(8 * 4 * 512 + 16 * 516) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)avgpool_fc1_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)avgpool_fc1_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  const dim3 grid(N / 256, (B + 7) / 8);
-  if (dtype == 0) hipLaunchKernelGGL(avgpool_fc1_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, in, W1p, b1, feat, hidden, B, h, w, N);
-  else hipLaunchKernelGGL(avgpool_fc1_kernel<f16_t>, grid, dim3(256), lds, (hipStream_t)stream, in, W1p, b1, feat, hidden, B, h, w, N);
-  return hipGetLastError() == hipSuccess ? 1 : -1;
-}
+// (r03 built avgpool + fc.0 as ONE launch -- 8 images x 256 outputs per workgroup, bit-identical to the two launches -- and measured
+// 38.9 us against 8.5 + 16.0: the fusion multiplies either the pooling reads or the weight stream.  Removed in r04)
 
 // generic fallback when K % 16 != 0 or N % 16 != 0 (non-default backbone_out_dim)
 __global__ __launch_bounds__(256) void fc1_simple_kernel(const float* feat, const float* W1, const float* b1,

@@ -497,198 +497,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #undef ST_PH
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Register-pool form (r02, third pass).  The persistent kernel above still parks the 17 x 17 x 64 conv outputs in LDS (37 KB
-// written, 74 KB read back by the pool, a third barrier) -- with the MFMA phase removed it still takes 92 of its 141 us.  Here
-// the pool never leaves the registers: a workgroup owns 7 x 7 POOLED pixels (56 = 8 x 7), i.e. 15 x 15 conv outputs; one MFMA
-// pixel tile = one conv row (16 columns, 15 used), wave w owns conv rows 4w .. 4w+4 (rows 4, 8, 12 are computed twice, +20 %
-// MFMAs), so the three conv rows of a pooled row are three accumulator tiles of ONE lane (vertical max = v_pk_max on packed
-// 16-bit ReLU outputs) and the three conv columns of a pooled column are lanes c, c+1, c+2 of one 16-lane DPP row (horizontal
-// max = two row_shl moves).  Even lanes 0..12 end with pooled column lane/2 and store their 16 channels.  LDS = weights +
-// one window (41 KB: three workgroups per CU), two barriers per tile, same MFMA sequence per conv output as the kernels above.
-// MEASURED SLOWER and therefore off by default (option stem_regpool): 197 vs 150 us at B = 256 x 224 x 224, 983 vs 697 us at
-// 512 x 512 -- both kernels run at about twice their MFMA floor, so the +30 % MFMAs cost more than the LDS round trip saved.
-__device__ __forceinline__ unsigned dpp_row_shl(unsigned v, int n) {
-  return n == 1 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true)
-                : (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true);
-}
-
-template <typename T, int FMT>
-__global__ __launch_bounds__(256, 3) void stem_pool_regpool_kernel(const StemPoolP p) {
-  typedef typename Elem<T>::frag frag;
-  constexpr int W_BYTES = 7 * 64 * 64;
-  constexpr int PR = 39, PC = 42;
-  constexpr int MT = 5, NT = 4, NI = 7, TP = 7;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Ws = smem;
-  char* const Ps = smem + W_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, r16 = lane & 15;
-  const int G = gridDim.x, total = p.B * p.tiles_y * p.tiles_x;
-  const int lb = xcd_remap(blockIdx.x, G);
-
-  for (int i = wave; i < W_BYTES / 1024; i += 4) GLDS16((const char*)p.w + i * 1024 + lane * 16, Ws + i * 1024);
-
-  const bool stager = tid < 6 * PC;
-  const int st = min(tid, 6 * PC - 1);
-  const int r0 = st / PC, c = st - r0 * PC;
-  constexpr int estep = FMT == 0 ? 1 : 3;
-  const size_t img_elems = (size_t)3 * p.H * p.W;
-  const int plane = p.H * p.W;
-  unsigned raw[NI][3];
-  unsigned okmask = 0;
-  auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {
-    tx = tile % p.tiles_x; const int q = tile / p.tiles_x;
-    ty = q % p.tiles_y; img = q / p.tiles_y;
-  };
-  auto issue_loads = [&](int tile) {
-    int tx, ty, img;
-    tile_origin(tile, tx, ty, img);
-    const int py0 = 2 * (2 * (ty * TP) - 1) - 3, px0 = 2 * (2 * (tx * TP) - 1) - 3;
-    const int x = px0 + c;
-    const bool okx = x >= 0 && x < p.W;
-    const int xoffs = min(max(x, 0), p.W - 1) * estep;
-    okmask = 0;
-    int off[NI];
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int r = r0 + 6 * k, y = py0 + r;
-      if (okx && r < PR && y >= 0 && y < p.H) okmask |= 1u << k;
-      off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;
-    }
-    if constexpr (FMT == 0) {
-      const float* s = (const float*)p.x + (size_t)img * img_elems;
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        raw[k][0] = __builtin_bit_cast(unsigned, s[off[k]]); raw[k][1] = __builtin_bit_cast(unsigned, s[off[k] + plane]);
-        raw[k][2] = __builtin_bit_cast(unsigned, s[off[k] + 2 * plane]);
-      }
-    } else if constexpr (FMT == 3) {
-      const unsigned char* s = (const unsigned char*)p.x + (size_t)img * img_elems;
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        unsigned short w01; __builtin_memcpy(&w01, s + off[k], 2);
-        raw[k][0] = w01; raw[k][1] = s[off[k] + 2];
-      }
-    } else {
-      const unsigned short* s = (const unsigned short*)p.x + (size_t)img * img_elems;
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        unsigned w01; __builtin_memcpy(&w01, s + off[k], 4);
-        raw[k][0] = w01; raw[k][1] = s[off[k] + 2];
-      }
-    }
-  };
-  auto write_window = [&]() {
-    if (!stager) return;
-    constexpr bool same = (FMT == 1) == std::is_same<T, bf16_t>::value;
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      u32x2 px;
-      if constexpr (FMT == 0)
-        px = pack4<T>(__builtin_bit_cast(float, raw[k][0]), __builtin_bit_cast(float, raw[k][1]), __builtin_bit_cast(float, raw[k][2]));
-      else if constexpr (FMT == 3)
-        px = pack4<T>((float)(raw[k][0] & 0xffu) / 255.0f, (float)(raw[k][0] >> 8) / 255.0f, (float)raw[k][1] / 255.0f);
-      else if constexpr (same)
-        px = u32x2{raw[k][0], raw[k][1]};
-      else if constexpr (FMT == 1)
-        px = pack4<T>(to_f32(__builtin_bit_cast(bf16_t, (unsigned short)(raw[k][0] & 0xffffu))), to_f32(__builtin_bit_cast(bf16_t, (unsigned short)(raw[k][0] >> 16))),
-                      to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][1])));
-      else
-        px = pack4<T>(to_f32(__builtin_bit_cast(f16_t, (unsigned short)(raw[k][0] & 0xffffu))), to_f32(__builtin_bit_cast(f16_t, (unsigned short)(raw[k][0] >> 16))),
-                      to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][1])));
-      if (r0 + 6 * k < PR) *(u32x2*)(Ps + (tid + 6 * PC * k) * 8) = ((okmask >> k) & 1u) ? px : u32x2{0u, 0u};
-    }
-  };
-
-  // ---- MFMA geometry: pixel tile pt of wave w = conv row 4w + pt, column r16 (rows 15, 16 of wave 3 are never used)
-  int xo[MT];
-#pragma unroll
-  for (int pt = 0; pt < MT; ++pt) xo[pt] = (2 * (4 * wave + pt) * PC + 2 * r16) * 8 + g * 16;
-  const int wsw = (0x1320 >> ((r16 >> 2) * 4)) & 3;
-  const int wo_ = r16 * 64 + ((g ^ wsw) << 4);
-  f32x4 b4[NT];
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) b4[ct] = *(const f32x4*)(p.bias + g * 16 + ct * 4);
-
-  int tile = lb;
-  if (tile < total) { issue_loads(tile); write_window(); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (; tile < total; tile += G) {
-    int tx, ty, img;
-    tile_origin(tile, tx, ty, img);
-    const int cr0 = 2 * (ty * TP) - 1, cc0 = 2 * (tx * TP) - 1;
-    const bool has_next = tile + G < total;
-    if (has_next) issue_loads(tile + G);           // in flight during the MFMA phase
-    asm volatile("" ::: "memory");
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int pt = 0; pt < MT; ++pt)
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
-#pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-      frag wf[NT], xf[MT];
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) wf[ct] = *(const frag*)(Ws + ky * 4096 + ct * 1024 + wo_);
-#pragma unroll
-      for (int pt = 0; pt < MT; ++pt) xf[pt] = *(const frag*)(Ps + xo[pt] + ky * (PC * 8));
-#pragma unroll
-      for (int pt = 0; pt < MT; ++pt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[ct], xf[pt], acc[pt][ct]);
-    }
-    __syncthreads();                               // everyone is done reading the window
-    if (has_next) write_window();
-    // ---- ReLU + 16-bit pack per conv row, zero outside the feature map (neutral for a max over ReLU outputs)
-    u32x4 o[MT][2];
-    {
-      const int cc = cc0 + r16;
-      const bool colok = cc >= 0 && cc < p.Ws;
-#pragma unroll
-      for (int pt = 0; pt < MT; ++pt) {
-        const int cr = cr0 + 4 * wave + pt;
-        const bool ok = colok && cr >= 0 && cr < p.Hs;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int w2 = 0; w2 < 4; ++w2) {
-            const int ch = h * 8 + w2 * 2;
-            const unsigned v = pk_relu16<T>(pack2<T>(acc[pt][ch >> 2][ch & 3], acc[pt][(ch + 1) >> 2][(ch + 1) & 3]));
-            o[pt][h][w2] = ok ? v : 0u;
-          }
-      }
-    }
-    // ---- 3x3 / s2 max-pool in registers: pooled rows 2w (conv tiles 0..2) and 2w+1 (tiles 2..4); columns by DPP
-    const int ox = tx * TP + (r16 >> 1);
-    const bool lane_out = (r16 & 1) == 0 && r16 <= 2 * (TP - 1) && ox < p.Wq;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int pi = 2 * wave + half;              // pooled row inside the tile
-      if (pi >= TP) break;                         // wave 3 owns pooled row 6 only
-      const int oy = ty * TP + pi;
-      u32x4 m[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          unsigned v = pk_max16_nonneg(pk_max16_nonneg(o[2 * half][h][k], o[2 * half + 1][h][k]), o[2 * half + 2][h][k]);
-          v = pk_max16_nonneg(pk_max16_nonneg(v, dpp_row_shl(v, 1)), dpp_row_shl(v, 2));
-          m[h][k] = v;
-        }
-      if (lane_out && oy < p.Hq) {
-        char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + g * 16) * 2;
-        *(u32x4*)dst = m[0];
-        *(u32x4*)(dst + 16) = m[1];
-      }
-    }
-    __syncthreads();                               // the next window is complete in LDS
-  }
-}
+// (r02 also built a register-pool form -- 7 x 7 pooled pixels per workgroup, pooling by v_pk_max across accumulator tiles and DPP
+// row shifts, no conv-output buffer in LDS, three workgroups per CU.  Bit-identical and slower: 197 vs 150 us at 224 x 224, 983 vs
+// 697 us at 512 x 512 (+30 % MFMAs for the conv rows computed twice).  Removed in r04; numbers in DESIGN.md 4.2.)
 
 extern "C" size_t flope_stem_pool_lds() { return 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16; }
 
@@ -696,15 +507,13 @@ extern "C" int flope_stem_pool_init() {
   hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)stem_pool_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-#define PA(T_, F_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_regpool_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+#define PA(T_, F_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   PA(bf16_t, 0) PA(bf16_t, 1) PA(bf16_t, 2) PA(bf16_t, 3) PA(f16_t, 0) PA(f16_t, 1) PA(f16_t, 2) PA(f16_t, 3)
 #undef PA
   return (int)e;
 }
 
 // persist_blocks > 0: a persistent kernel on that many workgroups; 0: one workgroup per tile.
-// regpool != 0 (with persist_blocks > 0): the register-pool kernel (7 x 7 pooled pixels per tile, three workgroups per CU)
 #ifdef FLOPE_STAG_DBG
 static unsigned long long* g_stem_dbg = nullptr;
 extern "C" void flope_stem_pool_set_dbg(void* ptr) { g_stem_dbg = (unsigned long long*)ptr; }
@@ -712,7 +521,7 @@ extern "C" void flope_stem_pool_set_dbg(void* ptr) { g_stem_dbg = (unsigned long
 
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq,
                                       int Wq, const void* w, const float* bias, void* out, int dtype, int persist_blocks,
-                                      int regpool, void* stream) {
+                                      void* stream) {
   StemPoolP p;
 #ifdef FLOPE_STAG_DBG
   p.dbg = g_stem_dbg;
@@ -723,17 +532,6 @@ extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H
   flope_host::fastdiv_magic((unsigned)p.tiles_x, &p.mg_tx, &p.sh_tx);
   flope_host::fastdiv_magic((unsigned)p.tiles_y, &p.mg_ty, &p.sh_ty);
   const dim3 block(256);
-  if (persist_blocks > 0 && regpool) {
-    p.tiles_y = (Hq + 6) / 7; p.tiles_x = (Wq + 6) / 7;
-    const int total = B * p.tiles_y * p.tiles_x;
-    const dim3 pgrid(persist_blocks < total ? persist_blocks : total);
-    const size_t plds = flope_stem_pool_lds();
-#define PL(T_, F_) hipLaunchKernelGGL((stem_pool_regpool_kernel<T_, F_>), pgrid, block, plds, (hipStream_t)stream, p)
-    if (dtype == 0) { if (in_format == 0) PL(bf16_t, 0); else if (in_format == 1) PL(bf16_t, 1); else if (in_format == 2) PL(bf16_t, 2); else PL(bf16_t, 3); }
-    else            { if (in_format == 0) PL(f16_t, 0); else if (in_format == 1) PL(f16_t, 1); else if (in_format == 2) PL(f16_t, 2); else PL(f16_t, 3); }
-#undef PL
-    return (int)hipGetLastError();
-  }
   if (persist_blocks > 0) {
     const int total = B * p.tiles_y * p.tiles_x;
     const dim3 pgrid(persist_blocks < total ? persist_blocks : total);

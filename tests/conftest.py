@@ -37,7 +37,7 @@ def ref_fixtures():
 @pytest.fixture(scope="session")
 def harness():
     import ctypes
-    path = os.path.join(ROOT, "tests", "host_harness", "libflope_host_harness.so")
+    path = os.environ.get("FLOPE_HOST_HARNESS") or os.path.join(ROOT, "tests", "host_harness", "libflope_host_harness.so")   # override: the -fsanitize build (make asan)
     if not os.path.exists(path):
         import subprocess
         subprocess.check_call(["make", "-C", ROOT, "tests/host_harness/libflope_host_harness.so"])

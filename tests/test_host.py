@@ -348,3 +348,55 @@ def test_integer_relu_clamp_equals_the_float_form_for_every_float16_pattern():
     x = np.maximum(x, np.float32(-65504.0))
     ref = x.astype(np.float16).view(np.uint16)
     assert np.array_equal(got, ref)
+
+
+def _w4_check(harness, nbd, pw, spread, mt, boundary, res, formula):
+    msg = C.create_string_buffer(256)
+    rc = harness.flope_host_w4_schedule_check(nbd, pw, spread, mt, boundary, res, formula, msg, 256)
+    return rc, msg.value.decode()
+
+
+def test_conv_w4_wait_counts_cover_every_lds_read(harness):
+    """conv_w4's `s_waitcnt vmcnt(N)` counts (flope_amd/csrc/w4_sched.h: a constexpr model of the wave's in-order memory queue, the
+    SAME functions the kernel instantiates) replayed against an independent statement of the schedule (tests/host_harness): for every
+    instantiated ring depth / patch size / burst spreading / tile height, inside a tile, behind a class walk's tile boundary (epilogue
+    stores in the queue) and in a class walk's last body with a residual input (register loads in the queue), every LDS read is
+    ordered behind a wait + barrier that covers its producing DMA.  Timing can never show a count that is too lax (the data has
+    usually landed anyway): r03 shipped one for a round -- the last two assertions replay exactly that bug."""
+    for nbd in (3, 4, 5):
+        for pw in (8, 10, 12):
+            for spread in (0, 1, 2, 3, 4):
+                for mt in (4, 5, 6, 7, 8):
+                    for boundary in (0, 1):
+                        for res in (0, 1):
+                            rc, msg = _w4_check(harness, nbd, pw, spread, mt, boundary, res, 0)
+                            assert rc == 0, (nbd, pw, spread, mt, boundary, res, msg)
+            # r03's closed form (one burst per half-chunk) describes the same schedule and passes ...
+            assert _w4_check(harness, nbd, pw, 0, 7, 0, 0, 1)[0] == 0
+    # ... and the expression it replaced lets the burst of double step 0 stay in flight across barrier 3 of a 5-deep ring,
+    # behind which its first fragments are read: the check names it (a shallower ring never had the problem)
+    rc, msg = _w4_check(harness, 5, 8, 0, 7, 0, 0, 2)
+    assert rc != 0 and "barrier 3" in msg and "patch buffer 1" in msg, msg
+    assert _w4_check(harness, 4, 8, 0, 7, 0, 0, 2)[0] == 0
+
+
+def test_conv_w4_queue_model_is_not_stricter_than_the_closed_form(harness):
+    """With the cold burst issued whole (spread <= 1) the queue model must reproduce r03's hand-derived counts exactly -- a model
+    that over-waits would pass the coverage test and silently cost time."""
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent("""
+        #include "w4_sched.h"
+        #include <cstdio>
+        int main() {
+          for (int pd = 2; pd <= 4; ++pd) for (int pw = 8; pw <= 12; pw += 2) for (int d = 0; d < 9; ++d)
+            if (w4_wait_n(d, pd, pw, 0, 0, 0) != w4_wait_n_r03(d, pd, pw)) { printf("%d %d %d: %d vs %d\\n", pd, pw, d, w4_wait_n(d, pd, pw, 0, 0, 0), w4_wait_n_r03(d, pd, pw)); return 1; }
+          static_assert(w4_wait_n(3, 4, 8, 0, 0, 0) == 8 && w4_wait_n(1, 4, 8, 0, 0, 0) == 16 && w4_wait_n(0, 4, 8, 0, 14, 0) == 22, "constexpr");
+          return 0;
+        }""")
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "m.cpp")
+        open(f, "w").write(src)
+        exe = os.path.join(td, "m")
+        subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "flope_amd", "csrc"), "-o", exe, f])
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout

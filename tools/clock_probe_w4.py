@@ -24,7 +24,7 @@ for kv in (sys.argv[2].split(",") if len(sys.argv) > 2 else []):
     k, v = kv.split("=")
     e.set_option(k, int(v))
 e.load_state_dict(sd)
-e.set_option("dbg", 64 | int(os.environ.get("ABL", 0)))   # ABL=1: no weight DMA in the loop, 2: no patch DMA (timing only)
+e.set_option("dbg", 64 | int(os.environ.get("ABL", 0)))   # ABL=1: no weight DMA in the loop, 2: no patch DMA (timing only), 256: per-double-step stamps of a FIRST body
 t0 = time.time()
 while time.time() - t0 < 2.5:
     for _ in range(50):
@@ -54,7 +54,7 @@ for i in (6, 7, 8, 11, 12, 13, 16, 17, 18):
     two = (bb[:, 4] > bb[:, 0]) & (bb[:, 5] > bb[:, 4])
     if two.any():
         t = bb[two]
-        print("          boundary (persistent, first): epilogue %.0f | wait next patch %.0f | table exchange %.0f | acc + shortcut + first reads %.0f | second tile loop %.0f   (%d wg)"
+        print("          boundary (class walk, first): epilogue %.0f | pointer bumps %.0f | accumulator init %.0f | shortcut + fragment reload %.0f | second tile loop %.0f   (%d wg)"
               % (np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2] - t[:, 1]), np.median(t[:, 3] - t[:, 2]), np.median(t[:, 4] - t[:, 3]), np.median(t[:, 5] - t[:, 4]), int(two.sum())))
     buf4 = np.zeros(1024 * 32, dtype=np.uint32)
     e.lib.flope_debug_read_ws(e.handle, buf4.ctypes.data_as(C.c_void_p), C.c_size_t(i * 1048576 + 196608), C.c_size_t(buf4.nbytes))
@@ -62,8 +62,16 @@ for i in (6, 7, 8, 11, 12, 13, 16, 17, 18):
     if dv[:, 1].any():
         wait = (dv[:, 1:18:2] - dv[:, 0:18:2]) & 0xffffffff          # per double step: DMA wait + barrier
         work = (dv[:, 2:18:2] - dv[:, 1:17:2]) & 0xffffffff          # behind barrier D .. in front of wait D + 1: 64 MFMA (floor 1024)
-        print("          last body, per double step D=0..8: wait+barrier " + " ".join("%4d" % v for v in np.median(wait, axis=0)))
+        print("          %s body, per double step D=0..8: wait+barrier " % ("first" if int(os.environ.get("ABL", 0)) & 256 else "last") + " ".join("%4d" % v for v in np.median(wait, axis=0)))
         print("                                    B(D) + A(D+1) 64 MFMA " + " ".join("%4d" % v for v in np.median(work, axis=0)))
+    if int(os.environ.get("ABL", 0)) & 512:
+        buf5 = np.zeros(1024 * 16, dtype=np.uint32)
+        e.lib.flope_debug_read_ws(e.handle, buf5.ctypes.data_as(C.c_void_p), C.c_size_t(i * 1048576 + 327680), C.c_size_t(buf5.nbytes))
+        gw = buf5.reshape(-1, 16)[: r.shape[0]][ok].astype(np.int64)
+        ref = dv[:, 13:14]                                           # behind barrier 6
+        rel = (gw - ref) & 0xffffffff
+        print("          D = 6 second sub-step, cycles since barrier 6 behind MFMA group 0..7: " + " ".join("%5d" % v for v in np.median(rel[:, :8], axis=0)))
+        print("          D = 7 first  sub-step,                                  group 0..7: " + " ".join("%5d" % v for v in np.median(rel[:, 8:], axis=0)))
     print(f"conv {i:2d}: {int(ok.sum()):4d} wg  pre {np.median(pre):7.0f}  loop {np.median(loop):8.0f}  post {np.median(post):7.0f}  "
           f"clock {np.median(clk):.3f} GHz ({clk.min():.2f}-{clk.max():.2f})")
 e.close()
