@@ -28,6 +28,10 @@ struct YConvP {
   int tile, tiles_x;                         // set by the launcher: LDS-staged 8 x 16 output tiles; tiles per row
   int wlds, pad2_;                           // set by the launcher: tile path with the weight image staged in LDS as well
   unsigned pw_mg, pw_sh;                     // n / (patch width) as multiply-shift
+  // float32 mode, exact-fp32 MFMA kernel (yolo_f32.hip y32m_conv_kernel): weights in A-fragment order of v_mfma_f32_16x16x4_f32,
+  // [channel block of 16 nt rows][k16 step][channel tile][lane = kq * 16 + row][4 k] (k = 16 step + 4 kq + element), rows permuted
+  // as in the 16-bit image; bias permuted the same way; k16 steps = ceil(k k Cin / 16)
+  const void* w32m; const float* bias32m; int k16steps, nt32m;
 };
 
 struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU) (+ add)

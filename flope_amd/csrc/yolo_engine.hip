@@ -47,11 +47,17 @@ extern "C" int flope_resize_linear_u8_launch(const uint8_t* in, int h, int w, ui
 extern "C" int flope_yread_launch(const void* src, int is_f32, int H, int W, int C, int ld, int dtype, float* dst, void* stream);
 // strict float32 mode (yolo_f32.hip): the same graph on float32 maps, plain fused-multiply-add convolutions
 extern "C" int flope_y32_conv_launch(const YConvP* p, void* stream);
+extern "C" int flope_y32m_conv_launch(const YConvP* p, void* stream);
+extern "C" int flope_y32m_multi_add_conv(YMultiP* m, const YConvP* p);
+extern "C" int flope_y32m_multi_add_dw(YMultiP* m, const YDwP* p);
+extern "C" int flope_y32m_multi_launch(const YMultiP* m, const YMultiP* m_dev, void* stream);
 extern "C" int flope_y32_dw_launch(const YDwP* p, void* stream);
 extern "C" int flope_y32_pool_launch(const YPoolP* p, void* stream);
 extern "C" int flope_y32_up_launch(const YUpP* p, void* stream);
 extern "C" int flope_y32_attn_init();
+extern "C" int flope_y32_pool_init();
 extern "C" int flope_y32_attn_launch(const YAttnP* p, void* stream);
+extern "C" int flope_y32m_attn_launch(const YAttnP* p, void* stream);
 extern "C" int flope_y32_letter_launch(const YLetterP* p, void* stream);
 
 using namespace flope_host;
@@ -107,6 +113,7 @@ struct flope_yolo {
   // than the overlap returned (1.31 ms; removed).  What does pay is putting the independent ops of one dependency level
   // into ONE grid (ymulti_kernel): option "batch", default on.
   int opt_batch = 1;
+  int opt_f32mfma = 1;                                        // float32 mode: convolutions on the exact-fp32 MFMA kernel (0: the plain fused-multiply-add kernels, its checker)
   int opt_bneck = 1;                                          // 1: Bottleneck pairs as one fused launch (ybneck_kernel); 0: two conv launches
   int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
   struct Captured { GraphKey key; hipGraphExec_t exec; hipEvent_t done; };   // done: recorded behind the last replay
@@ -199,7 +206,7 @@ struct Builder {
   // MFMA D rows 4g..4g+3 of channel tile ct are channels g*4nt + 4ct .. +3; k = tap * cin_pad + ci, zero padded to 32;
   // stored in MFMA A-fragment order [channel block][k step][channel tile][lane = kq * 16 + row][8 k]: a wave-load is 1 KiB
   void pack(const std::vector<float>& wf, const std::vector<float>& bf, int cout_, int cin, int cin_pad, int k, int nt,
-            const void** w_dev, const float** b_dev, int* ksteps) {
+            const void** w_dev, const float** b_dev, int* ksteps, const void** w32m = nullptr, const float** b32m = nullptr, int* k16steps = nullptr) {
     if (f32()) {            // strict mode: float32 [rows][tap * cin_pad + ci], rows in channel order (yolo_f32.hip)
       const int K = k * k * cin_pad;
       std::vector<float> w((size_t)cout_ * K, 0.f);
@@ -207,6 +214,22 @@ struct Builder {
         for (int tap = 0; tap < k * k; ++tap)
           for (int ci = 0; ci < cin; ++ci) w[(size_t)co * K + tap * cin_pad + ci] = wf[((size_t)co * cin + ci) * k * k + tap];
       *w_dev = upload(w); *b_dev = (const float*)upload(bf); *ksteps = (K + 31) / 32;
+      if (w32m) {           // ... and the image of the exact-fp32 MFMA kernel (yolo.h: YConvP::w32m), rows permuted as below
+        const int CB = 16 * nt, rows = (cout_ + CB - 1) / CB * CB, K16 = (K + 15) / 16;
+        std::vector<float> wm((size_t)rows * K16 * 16, 0.f), bm(rows, 0.f);
+        for (int r = 0; r < rows; ++r) {
+          const int blk = r / CB, in = r % CB, ct = in / 16, rr = in % 16, g = rr >> 2, q = rr & 3;
+          const int co = blk * CB + g * 4 * nt + ct * 4 + q;
+          if (co >= cout_) continue;
+          bm[r] = bf[co];
+          for (int tap = 0; tap < k * k; ++tap)
+            for (int ci = 0; ci < cin; ++ci) {
+              const int kk = tap * cin_pad + ci, ks = kk / 16, kq = (kk % 16) / 4, el = kk % 4;
+              wm[((((size_t)blk * K16 + ks) * nt + ct) * 64 + kq * 16 + rr) * 4 + el] = wf[((size_t)co * cin + ci) * k * k + tap];
+            }
+        }
+        *w32m = upload(wm); *b32m = (const float*)upload(bm); *k16steps = K16;
+      }
       return;
     }
     const int CB = 16 * nt, rows = (cout_ + CB - 1) / CB * CB, K = k * k * cin_pad, Kp = (K + 31) / 32 * 32;
@@ -256,7 +279,8 @@ struct Builder {
     const int rows = out_mode == 2 ? 4 * (co / 4) : co;
     op.nt = pick_nt(out_mode == 2 ? co / 4 : co);
     YConvP& c = op.conv; memset(&c, 0, sizeof c);
-    pack(wf, bf, rows, cin, in.C, k, op.nt, &c.w, &c.bias, &c.ksteps);
+    pack(wf, bf, rows, cin, in.C, k, op.nt, &c.w, &c.bias, &c.ksteps, &c.w32m, &c.bias32m, &c.k16steps);
+    c.nt32m = op.nt;
     c.in = vptr(in); c.Hi = vH(in); c.Wi = vW(in); c.Cin = in.C; c.ldi = vld(in);
     const int Ho = (c.Hi + 2 * (k / 2) - k) / stride + 1, Wo = (c.Wi + 2 * (k / 2) - k) / stride + 1;
     c.Ho = Ho; c.Wo = Wo; c.M = Ho * Wo; c.Cout = co;
@@ -439,11 +463,11 @@ struct Builder {
 int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
   if (e->dtype == FLOPE_DT_F32) {
     switch (op.kind) {
-      case Op::CONV: return flope_y32_conv_launch(&op.conv, st);
+      case Op::CONV: return e->opt_f32mfma ? flope_y32m_conv_launch(&op.conv, st) : flope_y32_conv_launch(&op.conv, st);
       case Op::DW: return flope_y32_dw_launch(&op.dw, st);
       case Op::POOL: return flope_y32_pool_launch(&op.pool, st);
       case Op::UP: return flope_y32_up_launch(&op.up, st);
-      case Op::ATTN: return flope_y32_attn_launch(&op.attn, st);
+      case Op::ATTN: return e->opt_f32mfma ? flope_y32m_attn_launch(&op.attn, st) : flope_y32_attn_launch(&op.attn, st);
       case Op::BNECK: return (int)hipErrorInvalidValue;      // never built in this mode
     }
   }
@@ -462,11 +486,13 @@ int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
   return (int)hipErrorInvalidValue;
 }
 
-// strict float32 mode runs the program-order schedule only (one launch per op of the ultralytics yaml)
-inline int sched_index(const flope_yolo* e) { return (e->opt_batch && e->dtype != FLOPE_DT_F32) ? 1 : 0; }
+// float32 mode: the level-batched schedule belongs to the MFMA kernels; their checker (f32mfma = 0) runs in program order, one
+// launch per op of the ultralytics yaml
+inline int sched_index(const flope_yolo* e) { return (e->opt_batch && (e->dtype != FLOPE_DT_F32 || e->opt_f32mfma)) ? 1 : 0; }
 
 int launch_one(flope_yolo* e, const Launch& L, hipStream_t st) {
-  return L.op >= 0 ? launch_op(e, e->ops[L.op], st) : flope_ymulti_launch(&L.multi, L.multi_dev, e->dtype, st);
+  if (L.op >= 0) return launch_op(e, e->ops[L.op], st);
+  return e->dtype == FLOPE_DT_F32 ? flope_y32m_multi_launch(&L.multi, L.multi_dev, st) : flope_ymulti_launch(&L.multi, L.multi_dev, e->dtype, st);
 }
 
 std::string launch_name(const flope_yolo* e, const Launch& L) {
@@ -507,7 +533,7 @@ int build_schedules(flope_yolo* e) {
   }
   e->sched[0].clear(); e->sched[1].clear();
   for (int i = 0; i < n; ++i) { Launch L; L.op = i; e->sched[0].push_back(L); }
-  if (e->dtype == FLOPE_DT_F32) return FLOPE_OK;             // no batched grids in the strict mode
+  const bool f32 = e->dtype == FLOPE_DT_F32;
   for (int lv = 0; lv < depth; ++lv) {
     // one grid's dynamic LDS is that of its hungriest op, so a fused Bottleneck (up to 134 KB) leaves the plain convs it shares a
     // grid with one workgroup per CU -- measured, sharing still wins (0.741 vs 0.757 ms per frame: a launch less per level);
@@ -529,7 +555,8 @@ int build_schedules(flope_yolo* e) {
         memset(&L.multi, 0, sizeof L.multi);
         for (size_t k = 0; k < m; ++k) {
           const Op& op = e->ops[batchable[at + k]];
-          const int s = op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt)
+          const int s = f32 ? (op.kind == Op::CONV ? flope_y32m_multi_add_conv(&L.multi, &op.conv) : flope_y32m_multi_add_dw(&L.multi, &op.dw))
+                      : op.kind == Op::CONV ? flope_ymulti_add_conv(&L.multi, &op.conv, op.nt)
                       : op.kind == Op::DW ? flope_ymulti_add_dw(&L.multi, &op.dw)
                                           : flope_ymulti_add_bneck(&L.multi, &op.conv, op.nt, &op.conv2, op.nt2);
           if (s) return yfail(e, FLOPE_EINVAL, "schedule: cannot batch " + op.name);
@@ -579,7 +606,7 @@ extern "C" int flope_yolo_create(int device_id, int frame_h, int frame_w, int im
   e->top = (int)nearbyint(dh - 0.1); e->left = (int)nearbyint(dw - 0.1);
   e->h = e->nh + e->top + (int)nearbyint(dh + 0.1); e->w = e->nw + e->left + (int)nearbyint(dw + 0.1);
   if (e->h % 32 || e->w % 32) { delete e; return yfail(nullptr, FLOPE_EINVAL, "flope_yolo_create: letterboxed size is not a multiple of 32"); }
-  if (hipSetDevice(device_id) != hipSuccess || flope_yattn_init() != 0 || flope_y32_attn_init() != 0) { delete e; return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: device setup failed"); }
+  if (hipSetDevice(device_id) != hipSuccess || flope_yattn_init() != 0 || flope_y32_attn_init() != 0 || flope_y32_pool_init() != 0) { delete e; return yfail(nullptr, FLOPE_EHIP, "flope_yolo_create: device setup failed"); }
   *out = e;
   return FLOPE_OK;
 }
@@ -801,7 +828,7 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   GraphKey key;
   memset(&key, 0, sizeof key);                              // the struct has tail padding and is compared bytewise
   key.frame = frame_dev; key.det = det_dev; key.count = count_dev; key.mask = mask_dev; key.conf = conf; key.iou = iou;
-  key.max_det = max_det; key.batch = e->opt_batch * 4 + e->opt_bneck; key.generic_attn = e->opt_generic_attn;
+  key.max_det = max_det; key.batch = e->opt_batch * 4 + e->opt_bneck + e->opt_f32mfma * 16; key.generic_attn = e->opt_generic_attn;
   hipGraphExec_t exec = nullptr;
   for (size_t i = 0; i < e->graphs.size(); ++i)
     if (memcmp(&key, &e->graphs[i].key, sizeof key) == 0) {
@@ -869,6 +896,7 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
     return prev;
   }
   if (!strcmp(name, "batch")) { const int prev = e->opt_batch; e->opt_batch = value != 0; return prev; }
+  if (!strcmp(name, "f32mfma")) { const int prev = e->opt_f32mfma; e->opt_f32mfma = value != 0; return prev; }
   if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
 }

@@ -248,22 +248,185 @@ extern "C" int flope_y32_dw_launch(const YDwP* p, void* stream) {
   hipLaunchKernelGGL(y32_dw_kernel, dim3((p->H * p->W * p->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
 }
+// r04: the same maxima, separably -- the window of the r-th cascaded pool is (4 r + 5)^2, its maximum the column maximum of row
+// maxima: a workgroup of 1024 threads takes 4 channels of the whole map into LDS, forms the row maxima of half-widths 2, 4, 6 there and the column
+// maxima from those (13 + 27 LDS reads per output instead of 169 global ones; max is exact in any order: bit-identical to the sweep
+// above, which stays for maps beyond LDS).
+template <int N>
+__global__ __launch_bounds__(1024) void y32_pool_lds_kernel(const YPoolP p) {
+  extern __shared__ float PL[];                          // [4][H * W][4]: the slab (4 channels), then its row maxima for half-widths 2, 4, 6
+  const int HW = p.H * p.W, c0 = blockIdx.x * 4;
+  for (int pix = threadIdx.x; pix < HW; pix += 1024)
+    *(f32x4*)(PL + pix * 4) = *(const f32x4*)((const float*)p.in + (size_t)pix * p.ldi + c0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW * 4; i += 1024) {
+    const int pix = i >> 2, c = i & 3, y = pix / p.W, x = pix - y * p.W;
+    float m[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int dx = -2 * N; dx <= 2 * N; ++dx) {
+      const int ix = x + dx;
+      const float f = (unsigned)ix < (unsigned)p.W ? PL[(y * p.W + ix) * 4 + c] : -3.0e38f;
+      const int a = dx < 0 ? -dx : dx;
+      m[2] = fmaxf(m[2], f);
+      if (a <= 4) m[1] = fmaxf(m[1], f);
+      if (a <= 2) m[0] = fmaxf(m[0], f);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) PL[(size_t)(r + 1) * HW * 4 + i] = m[r];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW * 4; i += 1024) {
+    const int pix = i >> 2, c = i & 3, y = pix / p.W, x = pix - y * p.W;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const int hw = 2 * (r + 1);                         // half-width of pool r's window; its row maxima: array r, or (the last pool) array 2
+      const float* rm = PL + (size_t)((r == N - 1 ? 2 : r) + 1) * HW * 4;
+      float a = -3.0e38f;
+#pragma unroll
+      for (int dy = -2 * N; dy <= 2 * N; ++dy) {
+        if (dy < -hw || dy > hw) continue;
+        const int iy = y + dy;
+        a = fmaxf(a, (unsigned)iy < (unsigned)p.H ? rm[(iy * p.W + x) * 4 + c] : -3.0e38f);
+      }
+      ((float*)p.out)[(size_t)pix * p.ldo + r * p.C + c0 + c] = a;
+    }
+  }
+}
+
+extern "C" int flope_y32_pool_init() {
+  hipError_t e = hipFuncSetAttribute((const void*)y32_pool_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)y32_pool_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)y32_pool_lds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return (int)e;
+}
 extern "C" int flope_y32_pool_launch(const YPoolP* p, void* stream) {
   if (p->n < 1 || p->n > 3) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(y32_pool_kernel, dim3((p->H * p->W * p->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  const size_t lds = (size_t)4 * p->H * p->W * 4 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (lds <= 160 * 1024 && p->C % 4 == 0 && p->ldi % 4 == 0) {
+    if (p->n == 1) hipLaunchKernelGGL(y32_pool_lds_kernel<1>, dim3(p->C / 4), dim3(1024), lds, st, *p);
+    else if (p->n == 2) hipLaunchKernelGGL(y32_pool_lds_kernel<2>, dim3(p->C / 4), dim3(1024), lds, st, *p);
+    else hipLaunchKernelGGL(y32_pool_lds_kernel<3>, dim3(p->C / 4), dim3(1024), lds, st, *p);
+  } else
+    hipLaunchKernelGGL(y32_pool_kernel, dim3((p->H * p->W * p->C + 255) / 256), dim3(256), 0, st, *p);
   return (int)hipGetLastError();
 }
+
 extern "C" int flope_y32_up_launch(const YUpP* p, void* stream) {
   hipLaunchKernelGGL(y32_up_kernel, dim3((4 * p->H * p->W * p->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
 }
+
+// r04: the same attention on the exact-fp32 matrix instruction.  One workgroup = 16 queries of one head, four waves:
+//   1. scores  S^T[key][query] = K[key][:] . Q[query][:] (A = 16 key rows, B = the 16 queries, 8 MFMAs per key tile of 16; a wave takes
+//      every fourth key tile), x scale, into LDS as S[query][key] (row pitch N + 4 floats: the value pass reads it conflict-free);
+//   2. softmax over the keys, 16 lanes per query, exactly as above (max, expf, sum, p = e / l: softmax first, then the weighted sum);
+//   3. values  O^T[dim][query] = V^T[dim][key] . P^T[key][query] (A = 16 dims of V for 4 keys, B = P from LDS; a wave takes every
+//      fourth group of 4 keys; partial sums added in wave order through LDS).
+// 126 -> ~10 us on 920 tokens x 2 heads.  Other summation order than y32_attn_kernel (which stays as the checker: f32mfma = 0).
+__global__ __launch_bounds__(256) void y32m_attn_kernel(const YAttnP p) {
+  extern __shared__ float S32m[];                        // [16][N + 4] scores / probabilities, then [3][4][64][4] partial outputs
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, c16 = lane & 15;
+  const int h = blockIdx.y, q0 = blockIdx.x * 16;
+  const int pitch = ((p.N + 15) & ~15) + 4;
+  const float* const base = (const float*)p.qkv + (size_t)h * 128;
+  float* const red = S32m + 16 * pitch;
+  // 1. scores
+  f32x4 qf[2];
+  {
+    const float* qp = base + (size_t)min(q0 + c16, p.N - 1) * p.ld + kq * 4;
+    qf[0] = *(const f32x4*)qp; qf[1] = *(const f32x4*)(qp + 16);
+  }
+  const int ntile = (p.N + 15) >> 4;
+  for (int kt = wave; kt < ntile; kt += 4) {
+    const float* kp = base + (size_t)min(kt * 16 + c16, p.N - 1) * p.ld + 32 + kq * 4;
+    const f32x4 k0 = *(const f32x4*)kp, k1 = *(const f32x4*)(kp + 16);
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[s], qf[0][s], d, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[s], qf[1][s], d, 0, 0, 0);
+    // lane (kq, c16): keys kt * 16 + 4 kq + r of query c16
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = kt * 16 + 4 * kq + r < p.N ? d[r] * p.scale : -3.0e38f;
+    *(f32x4*)(S32m + c16 * pitch + kt * 16 + 4 * kq) = o;
+  }
+  __syncthreads();
+  // 2. softmax (thread = query tid >> 4, keys tid & 15, + 16, ...)
+  {
+    const int ql = tid >> 4, kl = tid & 15;
+    float* Sq = S32m + ql * pitch;
+    float mx = -3.0e38f;
+    for (int j = kl; j < p.N; j += 16) mx = fmaxf(mx, Sq[j]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    float l = 0.f;
+    for (int j = kl; j < p.N; j += 16) { const float e = expf(Sq[j] - mx); Sq[j] = e; l += e; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 16);
+    const float inv = 1.f / l;
+    for (int j = kl; j < ((p.N + 15) & ~15); j += 16) Sq[j] = j < p.N ? Sq[j] * inv : 0.f;
+  }
+  __syncthreads();
+  // 3. values: k4 step g covers keys 4 g .. 4 g + 3; lane (kq, c16): A = V[4 g + kq][ct * 16 + c16], B = P[query c16][4 g + kq]
+  f32x4 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ng = ((p.N + 15) & ~15) >> 2;
+  const float* const vb = base + 64 + c16;
+  for (int g0 = wave; g0 < ng; g0 += 16) {               // four groups of this wave per trip: 16 loads in flight
+    float av[4][4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + 4 * u, key = min(4 * g + kq, p.N - 1);
+      bv[u] = g < ng ? S32m[c16 * pitch + 4 * g + kq] : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) av[u][ct] = vb[(size_t)key * p.ld + ct * 16];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ct], bv[u], acc[ct], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) *(f32x4*)(red + (((wave - 1) * 4 + ct) * 64 + lane) * 4) = acc[ct];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const f32x4 r = *(const f32x4*)(red + ((w * 4 + ct) * 64 + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[ct][q] += r[q];
+    }
+  // lane (kq, c16): query c16, dims ct * 16 + 4 kq + r
+  if (q0 + c16 < p.N) {
+    float* o = (float*)p.out + (size_t)(q0 + c16) * p.ldo + h * 64 + 4 * kq;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) *(f32x4*)(o + ct * 16) = acc[ct];
+  }
+}
+
 extern "C" int flope_y32_attn_init() {
-  return (int)hipFuncSetAttribute((const void*)y32_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void*)y32_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)y32m_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return (int)e;
 }
 extern "C" int flope_y32_attn_launch(const YAttnP* p, void* stream) {
   const size_t lds = (size_t)16 * p->N * sizeof(float);
   if (p->N < 1 || lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(y32_attn_kernel, dim3((p->N + 15) / 16, p->heads), dim3(256), lds, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+extern "C" int flope_y32m_attn_launch(const YAttnP* p, void* stream) {
+  const size_t lds = ((size_t)16 * (((p->N + 15) & ~15) + 4) + 3 * 4 * 64 * 4) * sizeof(float);
+  if (p->N < 1 || lds > 160 * 1024 || p->ld % 4 || p->ldo % 4) return flope_y32_attn_launch(p, stream);
+  hipLaunchKernelGGL(y32m_attn_kernel, dim3((p->N + 15) / 16, p->heads), dim3(256), lds, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
 }
 extern "C" int flope_y32_letter_launch(const YLetterP* p, void* stream) {
@@ -272,5 +435,261 @@ extern "C" int flope_y32_letter_launch(const YLetterP* p, void* stream) {
 }
 extern "C" int flope_y32_mask_low_launch(const YMaskP* p, void* stream) {
   hipLaunchKernelGGL(y32_mask_low_kernel, dim3((p->mh * p->mw + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// r04: the float32 detector on the matrix cores.  v_mfma_f32_16x16x4_f32 takes float32 operands and accumulates in float32 --
+// each product-sum is an fmaf chain, bit for bit, at 64 FLOP / clock / SIMD (157 TFLOP/s on the chip: the rate of the vector
+// FMA the kernels above use, but issued by one instruction per 1024 multiply-adds instead of sixteen, and with the weights as a
+// shared operand instead of scalar loads per thread).  VERDICT r3 item 2a: the mode whose int16 boxes / uint8 mask EQUAL the
+// reference's float32 arithmetic (fast_pose_predictor.py:49-56) should not cost 12 x the 16-bit detector.
+//   D[channel][pixel] += W[channel][k] X[k][pixel], weights = A operand (16 rows x 4 k per instruction), 16 output pixels = B.
+//   A lane loads 16 bytes = 4 consecutive k of its row / its pixel and feeds element s to MFMA s of a 16-deep step on BOTH
+//   operands (the k order inside a step is permuted identically for A and B: fc1_kernel's trick, pool_head.hip).
+//   Wave tile: MP x 16 pixels x 16 NT channels, operands straight from L2 (every map of the detector fits the Infinity Cache, the
+//   weights L2), next step's loads in flight under the current step's MFMAs.  SPLITK (maps of a few thousand pixels with deep K):
+//   the four waves of a workgroup share one pixel tile and take every fourth k16 step; partial sums are added in wave order
+//   through LDS -- deterministic.  Same summation order per output in both forms only up to that split: float32 rounding noise of
+//   ~1e-7 relative against the plain kernel above (which stays as the checker: option f32mfma = 0), not bit equality.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int NT, int MP, bool SPLITK>
+__device__ __forceinline__ void y32m_conv_body(const YConvP& p, int bx, int by, float* red) {   // red (SPLITK): 3 x 64 x NT x MP x 4 floats of LDS
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kq = lane >> 4, c16 = lane & 15;
+  constexpr int CB = 16 * NT;
+  const int rows = p.out_mode == 2 ? 4 * p.dc : p.Cout;
+  const int blk = by;
+  const int m0 = (SPLITK ? bx : bx * 4 + wave) * (16 * MP);     // first pixel of this wave's tile
+  const int pad = p.k == 3 ? 1 : 0, kk2 = p.k * p.k, cin = p.Cin;
+  const float* const in = (const float*)p.in;
+  const f32x4m* const wb = (const f32x4m*)p.w32m + (size_t)blk * p.k16steps * NT * 64 + lane;
+  // this lane's pixel of each of the MP pixel tiles
+  int oy[MP], ox[MP];
+  bool pv[MP];
+#pragma unroll
+  for (int t = 0; t < MP; ++t) {
+    const int m = m0 + t * 16 + c16;
+    pv[t] = m < p.M;
+    const int mc = pv[t] ? m : p.M - 1;
+    oy[t] = mc / p.Wo; ox[t] = mc - oy[t] * p.Wo;
+  }
+  f32x4m acc[MP][NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const f32x4m b = (!SPLITK || wave == 0) ? *(const f32x4m*)(p.bias32m + blk * CB + ct * 16 + 4 * kq) : f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < MP; ++t) acc[t][ct] = b;
+  }
+  // operand loads of k16 step ks: this lane's 4 k values are ks * 16 + kq * 4 .. + 3 = (tap, ci .. ci + 3)  (Cin % 4 == 0)
+  auto load_x = [&](int ks, f32x4m (&x)[MP]) {
+    const int kk = ks * 16 + kq * 4;
+    int tap = fastdiv(kk >> 3, p.cg_mg, p.cg_sh);                               // kk / Cin = (kk / 8) / (Cin / 8)
+    const int ci = kk - tap * cin;
+    const bool tv = tap < kk2;                                                  // (the zero-padded tail of K)
+    tap = tv ? tap : 0;
+    const int ky = p.k == 3 ? (tap * 11) >> 5 : 0, kx = tap - ky * 3;           // tap / 3 for 0..8
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {
+      const int iy = oy[t] * p.stride - pad + ky, ix = ox[t] * p.stride - pad + kx;
+      const bool ok = tv && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
+      const f32x4m v = *(const f32x4m*)(in + (size_t)(iyc * p.Wi + ixc) * p.ldi + ci);
+      x[t] = ok ? v : f32x4m{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto load_w = [&](int ks, f32x4m (&w)[NT]) {
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) w[ct] = wb[(size_t)(ks * NT + ct) * 64];
+  };
+  // K loop in chunks of U k16 steps: the loads of chunk c + 1 are issued before the MFMAs of chunk c (operands come straight from
+  // L2: ~500-800 cycles per round trip, a step's MFMAs are 128-512 -- one step of look-ahead left the loop latency-bound)
+  const int kstep0 = SPLITK ? wave : 0, kinc = SPLITK ? 4 : 1;
+  constexpr int U = 2;                                    // (4: no gain for the deep launches, fewer resident waves for the wide ones: 1.26 vs 1.04 ms per frame)
+  f32x4m xa[U][MP], wa[U][NT], xb[U][MP], wbf[U][NT];
+  const int nsteps = p.k16steps;
+  auto load_chunk = [&](int ks0, f32x4m (&x)[U][MP], f32x4m (&w)[U][NT]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks_ = min(ks0 + u * kinc, nsteps - 1);      // (steps past the end re-load the last one; their MFMAs are skipped)
+      load_x(ks_, x[u]); load_w(ks_, w[u]);
+    }
+  };
+  auto mfma_chunk = [&](int ks0, const f32x4m (&x)[U][MP], const f32x4m (&w)[U][NT]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ks0 + u * kinc >= nsteps) break;                  // uniform
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < MP; ++t)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][ct][s], x[u][t][s], acc[t][ct], 0, 0, 0);
+    }
+  };
+  int ks = kstep0;
+  if (ks < nsteps) load_chunk(ks, xa, wa);
+  for (; ks < nsteps; ks += 2 * U * kinc) {
+    const bool n1 = ks + U * kinc < nsteps;
+    if (n1) load_chunk(ks + U * kinc, xb, wbf);
+    mfma_chunk(ks, xa, wa);
+    if (!n1) break;
+    if (ks + 2 * U * kinc < nsteps) load_chunk(ks + 2 * U * kinc, xa, wa);
+    mfma_chunk(ks + U * kinc, xb, wbf);
+  }
+  if constexpr (SPLITK) {                                  // partial sums of waves 1..3 -> LDS, wave 0 adds them in wave order
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < MP; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) *(f32x4m*)(red + ((((wave - 1) * MP + t) * NT + ct) * 64 + lane) * 4) = acc[t][ct];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int t = 0; t < MP; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          const f32x4m r = *(const f32x4m*)(red + (((w * MP + t) * NT + ct) * 64 + lane) * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[t][ct][q] += r[q];
+        }
+  }
+  // epilogue: lane (kq, c16) holds pixel c16 x rows blk * CB + kq * 4 NT + ct * 4 + q = 4 NT consecutive output rows
+  const int r0 = blk * CB + kq * 4 * NT;
+#pragma unroll
+  for (int t = 0; t < MP; ++t) {
+    if (!pv[t]) continue;
+    const int m = m0 + t * 16 + c16;
+    float v[4 * NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float a = acc[t][ct][q]; v[ct * 4 + q] = p.act ? silu32(a) : a; }
+    if (p.out_mode == 2) {                                 // ConvTranspose2d 2x2 s2: rows r0 .. lie in one (dy, dx) quadrant (dc % 16 == 0)
+      if (r0 >= rows) continue;
+      const int quad = r0 / p.dc, co = r0 - quad * p.dc;
+      const size_t opix = (size_t)(2 * oy[t] + (quad >> 1)) * (2 * p.Wo) + 2 * ox[t] + (quad & 1);
+      float* o = (float*)p.out + opix * p.ldo + co;
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) *(f32x4m*)(o + ct * 4) = f32x4m{v[ct * 4], v[ct * 4 + 1], v[ct * 4 + 2], v[ct * 4 + 3]};
+    } else {
+      if (p.res) {
+        const float* rp = (const float*)p.res + (size_t)m * p.ldr + r0;
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) if (r0 + i < rows) v[i] += rp[i];
+      }
+      float* o = (float*)p.out + (size_t)m * p.ldo + r0;
+      if (p.out_mode == 0 && r0 + 4 * NT <= rows) {        // map views: 16-byte aligned runs
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) *(f32x4m*)(o + ct * 4) = f32x4m{v[ct * 4], v[ct * 4 + 1], v[ct * 4 + 2], v[ct * 4 + 3]};
+      } else {                                             // prediction rows (odd pitch) and ragged channel counts
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) if (r0 + i < rows) o[i] = v[i];
+      }
+    }
+  }
+}
+
+template <int NT, int MP, bool SPLITK>
+__global__ __launch_bounds__(256) void y32m_conv_kernel(const YConvP p) {
+  __shared__ __attribute__((aligned(16))) float red[SPLITK ? 3 * 64 * NT * MP * 4 : 4];
+  y32m_conv_body<NT, MP, SPLITK>(p, blockIdx.x, blockIdx.y, red);
+}
+
+// the form a launch takes: split-K over the workgroup's waves where pixels are few and K is deep; else one 16-pixel tile per wave, two
+// where that still leaves two workgroups per CU.  -> grid (nbx, nby)
+static bool y32m_geometry(const YConvP* p, bool* splitk, int* mp, int* nbx, int* nby, int mp2_from = 32768) {
+  if ((p->k != 1 && p->k != 3) || p->Cin % 8 || p->M < 1 || !p->w32m || !p->bias32m || (p->nt32m != 1 && p->nt32m != 2 && p->nt32m != 4)) return false;
+  const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
+  *splitk = p->M <= 4096 && p->k16steps >= 8;
+  *mp = (!*splitk && p->M >= mp2_from) ? 2 : 1;          // (two pixel tiles per wave halve the weight loads per MFMA; inside a shared grid the other ops keep the CUs filled)
+  const int tiles = (p->M + 16 * *mp - 1) / (16 * *mp);
+  *nbx = *splitk ? tiles : (tiles + 3) / 4;
+  *nby = (rows + 16 * p->nt32m - 1) / (16 * p->nt32m);
+  return true;
+}
+
+// float32 detector convolution on the matrix cores; p->w32m / bias32m / k16steps / nt32m from the builder (yolo_engine.hip pack)
+extern "C" int flope_y32m_conv_launch(const YConvP* p, void* stream) {
+  bool splitk; int mp, nbx, nby;
+  if (!y32m_geometry(p, &splitk, &mp, &nbx, &nby)) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(NT_, MP_, SK_) hipLaunchKernelGGL((y32m_conv_kernel<NT_, MP_, SK_>), dim3(nbx, nby), dim3(256), 0, st, *p)
+#define GN(NT_) do { if (splitk) GO(NT_, 1, true); else if (mp == 2) GO(NT_, 2, false); else GO(NT_, 1, false); } while (0)
+  if (p->nt32m == 1) GN(1); else if (p->nt32m == 2) GN(2); else GN(4);
+#undef GN
+#undef GO
+  return (int)hipGetLastError();
+}
+
+// ---- several INDEPENDENT float32 ops of one dependency level in one grid (the counterpart of yolo.hip's ymulti_kernel: the Segment
+// head's branches, the Proto block beside them, the two 1x1 convs of a C3k ... are a few dozen workgroups each and cost a whole
+// dependent launch when queued alone).  Same table (YMultiP in device memory, uniform reads), op codes of their own:
+//   conv: (nt index 0 / 1 / 2) * 4 + (MP == 2 ? 2 : 0) + (split-K ? 1 : 0);   12: depthwise
+__device__ __forceinline__ void y32_dw_body(const YDwP& p, int lb) {
+  const int idx = lb * 256 + threadIdx.x;
+  if (idx >= p.H * p.W * p.C) return;
+  const int pix = idx / p.C, c = idx - pix * p.C;
+  const int y = pix / p.W, x = pix - y * p.W;
+  const int ci = p.blk ? (c / p.blk) * p.blk_stride + p.blk_off + c % p.blk : c;
+  float a = p.bias[c];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+    if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+    a = fmaf(((const float*)p.in)[(size_t)(iy * p.W + ix) * p.ldi + ci], p.w[t * p.C + c], a);
+  }
+  if (p.act) a = silu32(a);
+  if (p.add) a += ((const float*)p.add)[(size_t)pix * p.lda + c];
+  ((float*)p.out)[(size_t)pix * p.ldo + c] = a;
+}
+
+__global__ __launch_bounds__(256) void y32m_multi_kernel(const YMultiP* __restrict__ Pd) {
+  __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4 * 4];
+  const YMultiP& P = *Pd;
+  const int b = blockIdx.x;
+  int s = 0;
+  for (int i = 1; i < P.n; ++i) s = b >= P.op[i].start ? i : s;
+  const YMultiOp& o = P.op[s];
+  const int lb = b - o.start;
+  if (lb >= o.nblocks) return;
+  if (o.code == 12) { y32_dw_body(o.u.d, lb); return; }
+  const int by = lb / o.nbx, bx = lb - by * o.nbx;
+  switch (o.code) {
+    case 0: y32m_conv_body<1, 1, false>(o.u.c, bx, by, red); break;
+    case 1: y32m_conv_body<1, 1, true>(o.u.c, bx, by, red); break;
+    case 2: y32m_conv_body<1, 2, false>(o.u.c, bx, by, red); break;
+    case 4: y32m_conv_body<2, 1, false>(o.u.c, bx, by, red); break;
+    case 5: y32m_conv_body<2, 1, true>(o.u.c, bx, by, red); break;
+    case 6: y32m_conv_body<2, 2, false>(o.u.c, bx, by, red); break;
+    case 8: y32m_conv_body<4, 1, false>(o.u.c, bx, by, red); break;
+    case 9: y32m_conv_body<4, 1, true>(o.u.c, bx, by, red); break;
+    default: y32m_conv_body<4, 2, false>(o.u.c, bx, by, red); break;
+  }
+}
+
+extern "C" int flope_y32m_multi_add_conv(YMultiP* m, const YConvP* p) {
+  bool splitk; int mp, nbx, nby;
+  if (m->n >= kYMultiMax || !y32m_geometry(p, &splitk, &mp, &nbx, &nby)) return (int)hipErrorInvalidValue;
+  YMultiOp& o = m->op[m->n++];
+  o.code = (p->nt32m == 1 ? 0 : p->nt32m == 2 ? 4 : 8) + (mp == 2 ? 2 : 0) + (splitk ? 1 : 0);
+  o.nbx = nbx; o.start = m->total; o.nblocks = nbx * nby; o.u.c = *p;
+  m->total += (o.nblocks + 7) / 8 * 8;
+  return 0;
+}
+extern "C" int flope_y32m_multi_add_dw(YMultiP* m, const YDwP* p) {
+  if (m->n >= kYMultiMax) return (int)hipErrorInvalidValue;
+  YMultiOp& o = m->op[m->n++];
+  o.code = 12; o.nbx = 1; o.start = m->total; o.nblocks = (p->H * p->W * p->C + 255) / 256; o.u.d = *p;
+  m->total += (o.nblocks + 7) / 8 * 8;
+  return 0;
+}
+extern "C" int flope_y32m_multi_launch(const YMultiP* m, const YMultiP* m_dev, void* stream) {
+  if (!m_dev || m->n < 1 || m->n > kYMultiMax || m->total < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(y32m_multi_kernel, dim3(m->total), dim3(256), 0, (hipStream_t)stream, m_dev);
   return (int)hipGetLastError();
 }

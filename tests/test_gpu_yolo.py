@@ -461,6 +461,16 @@ def test_f32_strict_mode_integer_outputs_equal_the_fp32_oracle(ysd, H, W, imgsz,
     y.set_option("batch", 1)
     b2 = y.detect(img, conf)[0].astype(np.int16)
     assert np.array_equal(b2, bb)
+    # r04: everything above ran on the exact-fp32 MFMA convolutions (v_mfma_f32_16x16x4_f32, default).  The plain fused-multiply-add
+    # kernels (f32mfma = 0) are their checker: another summation order, so float32 round-off apart, the same integers
+    heads = {n: y.read_tensor(n).cpu() for n in ("22", "proto", "box0", "cls2", "coef1")}
+    assert y.set_option("f32mfma", 0) == 1
+    bx, cf, _, an, mk = y.detect(img, conf)
+    assert np.array_equal(bx.astype(np.int16), bb) and an.tolist() == ref["idx"].tolist()
+    assert np.count_nonzero(mk != mask) <= 8 * npix
+    for n, t in heads.items():
+        assert _rel(y.read_tensor(n).cpu(), t) <= 1e-5, n
+    assert y.set_option("f32mfma", 1) == 0
     import ctypes as C
     from flope_amd import _lib
     h = C.c_void_p()
