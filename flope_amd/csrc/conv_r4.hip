@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;                                   // 2 patch buffers
   char* const Ws = smem + 2 * PATCH_B;                     // resident weights: 18 x [64 rows][32 k]
+  // r04: a wave-private 2 KB LINE IMAGE per wave behind the weights.  A lane's accumulators are one pixel x two runs of 8 channels
+  // (MFMA order), so a wave-store / residual load touched 16 pixels x 64 bytes; through the image (XOR-swizzled, conflict-free both
+  // ways, LDS operations of a wave execute in order: no barrier) the 16-bit outputs leave as 8 whole
+  // 128-byte lines per instruction (conv_w4.hip; tools/probes/store_probe.hip: 4.2 k -> 2.9 k cycles per 64 KB).  Same bytes.
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
   const size_t pixB = (size_t)p.Cin * 2;                   // 128
   const size_t rowB = (size_t)p.Wip * pixB;
   const int cb = g * 8;                                    // this lane's channels: cb .. cb + 7 and cb + 32 .. cb + 39
+  char* const lscr = smem + 2 * PATCH_B + NSTEP * TILE_B + wave * 2048;   // this wave's line image
 
 #define R4_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define R4_BARRIER()                                                                                           \
@@ -79,15 +84,28 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
   static_assert(MT == 7, "conv_r4: the pixel-tile -> address-register map below is the one of 56-pixel rows");
   constexpr int kXB[7] = {0, 0, 0, 1, 2, 2, 2}, kXA[7] = {0, 1024, 2048, 0, 0, 1024, 2048}, kXP[3] = {0, 3, 4};
   int xoff[9][3];
-  unsigned oconst[MT];                                     // byte offset of this lane's pixel of tile pt relative to the band's first padded row
+  // byte offsets relative to the band's first padded output row, in LINE order: row pp = c * 8 + (lane >> 3) of pixel tile pt's line
+  // image is written by the lanes with r16 = pp, i.e. holds pixel pt * 16 + tile_px_r4(pp); this lane moves its 16-byte chunk lane & 7
+  unsigned osto[MT][2];
+  unsigned oconst[RES ? MT : 1];                           // RES: this lane's own pixel of tile pt (MFMA order): where its residual lives
   const int g4 = g << 4;
+  if constexpr (RES) {
 #pragma unroll
-  for (int pt = 0; pt < MT; ++pt) {
-    const int k = pt * 16 + pcol;                          // pixel index inside the wave's two rows
-    const int row = k >= Wo ? 1 : 0, col = k - row * Wo;
-    const int i_ = 2 * wave + row;                         // output row inside the band = patch row of tap dy = 0
-    oconst[pt] = (unsigned)((((i_ + 1) * p.Wop + col + 1) * p.Cout + cb) * 2);
+    for (int pt = 0; pt < MT; ++pt) {
+      const int k = pt * 16 + pcol;
+      const int row = k >= Wo ? 1 : 0, col = k - row * Wo;
+      oconst[pt] = (unsigned)((((2 * wave + row + 1) * p.Wop + col + 1) * p.Cout + cb) * 2);
+    }
   }
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = pt * 16 + tile_px_r4(c * 8 + (lane >> 3));   // pixel index inside the wave's two rows
+      const int row = k >= Wo ? 1 : 0, col = k - row * Wo;
+      const int i_ = 2 * wave + row;                       // output row inside the band = patch row of tap dy = 0
+      osto[pt][c] = (unsigned)((((i_ + 1) * p.Wop + col + 1) * p.Cout) * 2 + (lane & 7) * 16);
+    }
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     const int k = kXP[b] * 16 + pcol;
@@ -163,7 +181,9 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
         GLDS16(dsrc_ + psrc[2 * (P_) + 1], Ps + ((U_) == 0 ? PATCH_B : 0) + ((2 * (P_) + 1) * 256 + wave * 64) * 16); \
     }                                                                                                          \
     if constexpr (RES && (U_) >= 1 && (U_) <= MT && (P_) < 2) {   /* residual of pixel tile U_ - 1, half P_: one load per group */ \
-      const char* rp_ = rb + oconst[(U_) - 1 < MT ? (U_) - 1 : 0];                                             \
+      /* (MFMA order.  r04 tried line order + a hop through the line image: the launch got 3 us SLOWER -- 82.5 vs 79.5 us same-run; \
+         profiles/r04_conv_r4_line_order_ab.txt -- while line-order STORES gain 2 us on the launches without a residual) */ \
+      const char* rp_ = rb + oconst[(RES && (U_) - 1 < MT) ? (U_) - 1 : 0];                                    \
       if constexpr ((P_) == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[(U_) - 1 < MT ? (U_) - 1 : 0][0]) : "v"(rp_) : "memory"); \
       else asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(rq[(U_) - 1 < MT ? (U_) - 1 : 0][1]) : "v"(rp_) : "memory"); \
     }                                                                                                          \
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
     R4_SUB(17);
     R4_STAMP(5);
 
-    // ---- epilogue: (+ residual) (ReLU) -> 16-bit padded NHWC; accumulators back to the bias; next tile's residual
+    // ---- epilogue: (+ residual) (ReLU) -> 16-bit padded NHWC through the wave's line image; accumulators back to the bias
     char* const ob = (char*)p.out + (size_t)m0 * p.Wop * p.Cout * 2;
 #pragma unroll
     for (int pt = 0; pt < MT; ++pt) {
@@ -237,6 +257,9 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
       for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
+      const int pp0 = lane >> 3, pp1 = 8 + (lane >> 3);
+      char* const li0 = lscr + pp0 * 128 + (((lane & 7) ^ (pp0 & 7)) << 4);    // this lane's chunk of the image, line order (rows pp0, pp1)
+      char* const li1 = lscr + pp1 * 128 + (((lane & 7) ^ (pp1 & 7)) << 4);
       if constexpr (RES) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -251,7 +274,12 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = pk_out16<T>(pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]), p.relu);
-        *(u32x4*)(ob + oconst[pt] + c * 64) = o;
+        if constexpr (RES) *(u32x4*)(ob + oconst[pt] + c * 64) = o;      // (with a residual the launch is HBM-bound and the hop through the image only adds latency: +2..5 us same-run)
+        else *(u32x4*)(lscr + r16 * 128 + (((c * 4 + g) ^ (r16 & 7)) << 4)) = o;
+      }
+      if constexpr (!RES) {
+        *(u32x4*)(ob + osto[pt][0]) = *(const u32x4*)li0;
+        *(u32x4*)(ob + osto[pt][1]) = *(const u32x4*)li1;
       }
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = b4[ct];
@@ -301,7 +329,7 @@ extern "C" int flope_conv_r4_ok(const ConvP* p) {
 extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream) {
   if (!flope_conv_r4_ok(p) || !p->mg_pitch || grid_blocks < 1 || grid_blocks > p->total_tiles || p->tiles_per_image != p->Ho / 8)
     return (int)hipErrorInvalidValue;
-  const size_t lds = (size_t)2 * 5 * 8192 + 18 * 4096;
+  const size_t lds = (size_t)2 * 5 * 8192 + 18 * 4096 + 4 * 2048;      // patch buffers, resident weights, line images
   const dim3 grid(grid_blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) { if (p->res) hipLaunchKernelGGL((conv_r4_kernel<bf16_t, 7, 5, true>), grid, block, lds, st, *p); else hipLaunchKernelGGL((conv_r4_kernel<bf16_t, 7, 5, false>), grid, block, lds, st, *p); }
