@@ -104,7 +104,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -776,7 +776,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
           // launches fill what a coarse tiling leaves idle).  A launch that has the chip to itself (one slice: batches below 64, the
           // profile pass) gains another ~12 % from 192 / 160-pixel tiles where they save a round.
           const int cus = e->num_cus;
-          const int mt_lo = e->opt_w4mtlo ? e->opt_w4mtlo : (e->cur_slices == 1 ? 5 : 7);
+          const int mt_lo = e->opt_w4mtlo ? e->opt_w4mtlo : (e->plan_slices == 1 ? 5 : 7);
           auto cost = [&](int m) {
             const int t = (p.M + 32 * m - 1) / (32 * m) * p.ntiles;
             return (double)((t + cus - 1) / cus) * (15000.0 + dsteps * (128.0 * m + 500.0));
@@ -795,7 +795,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         // -14 %, layer 3 at 2 tiles -5 %); with two slices in flight +0.5 % -- 896 tiles of 224 pixels are 3.5 per CU, equal walks
         // leave 32 CUs idle where the one-tile-per-workgroup launches of the two slices fill each other's gaps.  So: where a launch
         // has the chip to itself (option w4cwf overrides).
-        if (e->opt_w4cw >= 2 && (e->cur_slices == 1 || (e->opt_w4cwf & 1)) && (e->opt_w4mt == 0 || e->opt_w4mt == 7) && c.w4_patch[7] && p.M % 224 == 0 &&
+        if (e->opt_w4cw >= 2 && (e->plan_slices == 1 || (e->opt_w4cwf & 1)) && (e->opt_w4mt == 0 || e->opt_w4mt == 7) && c.w4_patch[7] && p.M % 224 == 0 &&
             flope_conv_w4_lds(c.w4_patch[7], 7, p.ds_in ? 1 : 0, 1) != 0) {
           const long hw = (long)c.hout * c.wout;
           long a_ = hw, b_ = 224; while (b_) { const long t_ = a_ % b_; a_ = b_; b_ = t_; }   // gcd
@@ -877,8 +877,12 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   e->ev_n = 0;
   e->last_fused = e->opt_fuse_stem && e->dtype != FLOPE_DT_F32;
   e->last_batch = batch;
-  int ns = (e->opt_streams >= 2 && e->opt_profile != 1) ? e->opt_streams : 1;
+  int ns = e->opt_streams >= 2 ? e->opt_streams : 1;
   while (ns > 1 && batch / ns < 32) --ns;              // keep every slice large enough to fill the chip
+  // profile = 1 times every launch on ONE stream -- but with the kernel variants (tile heights, class walk) the production
+  // schedule of this batch picks, so that the per-launch table describes the kernels the un-profiled step runs
+  e->plan_slices = ns;
+  if (e->opt_profile == 1) ns = 1;
   e->cur_slices = ns;
   e->cur_batch = batch;
   e->mark_slice = 0;
@@ -902,7 +906,9 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
       // (option profile = 2, tools/slice_timeline.py): the two slices walk the same layers side by side and finish within
       // microseconds of each other -- the uneven sizes change the tile counts that share the chip, not the phase.
       int first = e->opt_split > 100 ? e->opt_split - 100 : (int)((long)batch * e->opt_split / 100);
-      if (e->opt_split == 0) first = batch >= 128 ? (batch * 3 / 8) & ~7 : batch / 2;
+      // r04: equal halves by default -- with the r04 kernels 128/128 beats 96/160 by 1 - 2.5 % in every autotune run
+      // (profiles/r04_autotune_runs.txt); PoseEngine.autotune still tries 3/8 and 7/16
+      if (e->opt_split == 0) first = batch >= 128 ? (batch / 2) & ~7 : batch / 2;
       first = std::max(1, std::min(batch - 1, first));
       start = s == 0 ? 0 : first; cnt = s == 0 ? first : batch - first;
     }
@@ -928,7 +934,7 @@ static int run_trunk(flope_engine* e, const void* x_dev, int in_format, int batc
   }
   if (rc_all != FLOPE_OK) {
     if (!first_err.empty()) { e->err = first_err; g_last_error = first_err; }
-    e->cur_slices = 1; e->cur_batch = 1; e->last_batch = 0;
+    e->cur_slices = 1; e->plan_slices = 1; e->cur_batch = 1; e->last_batch = 0;
   }
   return rc_all;
 }

@@ -177,6 +177,44 @@ class PoseEngine:
             _lib.check(rc, self.handle)
         return rc
 
+    # schedule candidates of autotune(): engine options whose best value differs from box to box and from batch to batch
+    # (same-run pairs move by up to +-2 %, and boxes of one pool differ by up to 12 % in clock)
+    # (one slice instead of two is not a candidate: below ~130 crops it would switch split-K on, which sums in another order)
+    TUNE_CANDIDATES = ({}, {"w4cw": 4, "w4cwf": 1}, {"lag": 0}, {"split": 38}, {"split": 44})
+
+    def autotune(self, x: torch.Tensor, fmt: int, rounds: int = 5, per_round: int = 5, candidates=None) -> dict:
+        """Pick the launch schedule for THIS device and THIS batch by measurement: every candidate option set runs `per_round`
+        forwards per round, candidates interleaved over `rounds` rounds (so that none of them owns the slow steps of a GPU that
+        is still ramping its clock up), timed with events on the caller's stream; the set with the smallest median step is left
+        in force.  ~rounds x per_round x len(candidates) forwards (a hundred milliseconds at B = 256).  Results do not depend on
+        the choice: every candidate is bit-identical (tests/test_gpu_parity.py)."""
+        cands = [dict(c) for c in (candidates if candidates is not None else self.TUNE_CANDIDATES)]
+        R = torch.empty((x.shape[0], 9), dtype=torch.float32, device=self.device)
+        self._check_into(x, fmt, R=(R, 9))
+        names = sorted({k for c in cands for k in c})
+        base = {k: self.set_option(k, 0) for k in names}                   # current values (set_option returns the previous one)
+        for k, v in base.items():
+            self.set_option(k, v)
+        times = [[] for _ in cands]
+        with torch.cuda.device(self.device):
+            for _ in range(rounds):
+                for ci, c in enumerate(cands):
+                    for k in names:
+                        self.set_option(k, c.get(k, base[k]))
+                    self.forward_into(x, fmt, None, R)                          # (first forward of a new option set: not timed)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(per_round):
+                        self.forward_into(x, fmt, None, R)
+                    e1.record()
+                    e1.synchronize()
+                    times[ci].append(e0.elapsed_time(e1) / per_round)
+        med = [sorted(t)[len(t) // 2] for t in times]
+        best = min(range(len(cands)), key=lambda i: med[i])
+        for k in names:
+            self.set_option(k, cands[best].get(k, base[k]))
+        return {"chosen": cands[best], "median_ms": {str(c): round(m, 4) for c, m in zip(cands, med)}}
+
     def flops(self, batch: int) -> float:
         return float(self.lib.flope_forward_flops(self.handle, batch))
 

@@ -284,6 +284,25 @@ def test_fc_rot_split_over_four_waves_equals_the_one_wave_kernel(state_dict, B, 
     e.close()
 
 
+def test_autotune_picks_a_candidate_and_changes_no_bit(state_dict):
+    """PoseEngine.autotune (bench.py's set-up step): times the schedule candidates on this device and leaves the fastest in force.
+    Every candidate computes the same bits, so the rotations before and after are identical; the report names the choice and a
+    median per candidate."""
+    torch.manual_seed(5)
+    B = 128
+    x = torch.rand(B, 224, 224, 3).to(torch.float16).cuda()
+    e = _engine(state_dict, 224, 224, B, "f16")
+    r9a, Ra = e.forward(x)
+    rep = e.autotune(x, 2, rounds=2, per_round=2)
+    assert rep["chosen"] in [dict(c) for c in e.TUNE_CANDIDATES] and len(rep["median_ms"]) == len(e.TUNE_CANDIDATES)
+    assert all(0.0 < v < 100.0 for v in rep["median_ms"].values())
+    for k, v in rep["chosen"].items():
+        assert e.set_option(k, v) == v                     # (the chosen values are the ones in force)
+    r9b, Rb = e.forward(x)
+    assert torch.equal(r9a, r9b) and torch.equal(Ra, Rb)
+    e.close()
+
+
 @pytest.mark.parametrize("B", [131, 200, 255])
 def test_slice_split_is_invisible(state_dict, B):
     """The internal two-slice split (3/8 : 5/8 on multiples of 8 images, row-band grids proportional to the slice) must
