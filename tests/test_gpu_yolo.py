@@ -44,15 +44,19 @@ def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol):
     got_in = y.read_tensor("input").cpu()
     assert torch.equal(got_in[:3], x[0].to(tdt).float()) and not got_in[3:].any()      # letterbox + BGR->RGB + /255: exact
     o = Y.forward_layers(ysd, x)
+    worst = [0.0, 0.0]
     for name in LAYERS:
         got = y.read_tensor(name).cpu()
         ref = o[int(name)][0]
         assert got.shape == ref.shape, name
+        worst[0] = max(worst[0], _rel(got, ref))
         assert _rel(got, ref) <= tol, (name, _rel(got, ref))
     for name in ["proto_up", "proto"] + [f"{k}{i}" for i in range(3) for k in ("box", "cls", "coef")]:
         got, ref = y.read_tensor(name).cpu(), o[name][0]
         assert got.shape == ref.shape, name
+        worst[1] = max(worst[1], _rel(got, ref))
         assert _rel(got, ref) <= 2 * tol, (name, _rel(got, ref))
+    print(f"detector {dtype} {H}x{W}/{imgsz}: worst rel-L2 of a graph output {worst[0]:.2e}, of a head row block {worst[1]:.2e}")
     y.close()
 
 
