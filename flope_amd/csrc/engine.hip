@@ -38,6 +38,9 @@ extern "C" int flope_conv_r4_ok(const ConvP* p);
 extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream);
 extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int grid_blocks, int mt, void* stream);
 extern "C" size_t flope_conv_w4_lds(int pt, int mt, int dsf, int pers);
+extern "C" int flope_conv_w8_init();
+extern "C" int flope_conv_w8_launch(const ConvP* p, int dtype, void* stream);
+extern "C" size_t flope_conv_w8_lds(int pt);
 extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
@@ -104,7 +107,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_w8 = 0;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -415,6 +418,7 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     if (s == 0) s = flope_conv_stag_init();
     if (s == 0) s = flope_conv_gstag_init();
     if (s == 0) s = flope_conv_w4_init();
+    if (s == 0) s = flope_conv_w8_init();
     if (s == 0) s = flope_conv_r4_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
@@ -547,6 +551,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
   else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = value != 0; return prev; }
+  else if (!strcmp(name, "w8")) { prev = e->opt_w8; e->opt_w8 = value != 0; return prev; }   // conv_w8 (8 waves, two per SIMD, 256-pixel tiles) in place of conv_w4
   else if (!strcmp(name, "w4cw")) { prev = e->opt_w4cw; e->opt_w4cw = value < 0 ? 0 : (value > 64 ? 64 : value); return prev; }   // conv_w4 class walk: tiles per persistent workgroup aimed at (0 / 1 = one tile per workgroup)
   else if (!strcmp(name, "w4cwf")) { prev = e->opt_w4cwf; e->opt_w4cwf = value & 3; return prev; }   // ... bit 0: also with several batch slices in flight, bit 1: also where the walk fills < 85 % of the slice's CUs
   else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
@@ -769,6 +774,13 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         // of the chip x the time of a tile -- ~15 k cycles of prologue + epilogue, and per double step 128 cycles of MFMAs per
         // pixel tile + ~500 of everything else (r03 stamps: 1.52 k at 8, 1.4 k at 7); ties go to the larger tile
         int mt = 8, ptr = c.stag_patch_bytes;
+        if (e->opt_w8 && flope_conv_w8_lds(ptr) != 0) {
+          fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
+          SMARK();
+          c.last_kernel = "conv_w8_kernel<256x128>"; c.last_detail = "[256 px tiles, 8 waves]";
+          K_TRY(e, c.name.c_str(), flope_conv_w8_launch(&p, dt, stream));
+          continue;
+        }
         if (e->opt_w4mt != 8) {
           const double dsteps = 9.0 * (c.cin / 64 + (p.ds_in ? 1 : 0));
           // Measured (profiles/r03_conv_w4_tile_height_ab.txt): with two batch slices in flight only 224 against 256 pays (+1.8 % on

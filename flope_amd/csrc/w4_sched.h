@@ -62,7 +62,7 @@ W4_HD constexpr int w4_patch_first(int D, int PW, int spread) {
 // which patch buffer the pieces of double step D fill (0 / 1), or -1
 W4_HD constexpr int w4_patch_buffer(int D, int PW, int spread) { return w4_patch_pieces(D, PW, spread) == 0 ? -1 : (D == 0 ? 1 : 0); }
 // DMA pieces of the second sub-step of double step D
-W4_HD constexpr int w4_pieces(int D, int PW, int spread) { return W4_TGW + w4_patch_pieces(D, PW, spread); }
+W4_HD constexpr int w4_pieces(int D, int PW, int spread, int tgw = W4_TGW) { return tgw + w4_patch_pieces(D, PW, spread); }
 
 // Class walk + residual input, LAST body: the tile's 2 MT residual loads (register loads by inline assembly) are issued in the FIRST
 // sub-steps of double steps 7 (8 loads) and 8 (the other 2 MT - 8), i.e. right in front of the waits of barriers 7 and 8.
@@ -77,11 +77,12 @@ W4_HD constexpr int w4_res_first(int MT) { return 8; }            // index of th
 //   double tiles were read there, its buffer-1 burst was due at its barrier 3, its buffer-0 burst at its barrier 8), this body's
 //   buffer-1 burst from D = 3 on, this body's buffer-0 pieces at D = 8.  Double tile k of the current body is issued at double step
 //   k - PD of the current body, or (k < PD) at double step 9 + k - PD of the body before.
-W4_HD constexpr int w4_wait_n(int D, int PD, int PW, int spread, int boundary_ops, int res_mt) {
+// (tgw: pieces of a double tile per wave -- 4 on the 4-wave kernel, 2 on the 8-wave one, conv_w8.hip)
+W4_HD constexpr int w4_wait_n(int D, int PD, int PW, int spread, int boundary_ops, int res_mt, int tgw = W4_TGW) {
   int issued = 0, last_needed = 0;                       // running count of issued operations; 1-based index of the youngest needed one
   // body -1 (everything needed; its double tiles 9 .. belong to the current body: index k = d + PD - 9)
   for (int d = 0; d < 9; ++d) {
-    for (int i = 0; i < W4_TGW; ++i) { ++issued; const int k = d + PD - 9; if (k <= D + 1) last_needed = issued; }
+    for (int i = 0; i < tgw; ++i) { ++issued; const int k = d + PD - 9; if (k <= D + 1) last_needed = issued; }
     for (int i = 0; i < w4_patch_pieces(d, PW, spread); ++i) { ++issued; last_needed = issued; }
   }
   issued += boundary_ops;
@@ -89,7 +90,7 @@ W4_HD constexpr int w4_wait_n(int D, int PD, int PW, int spread, int boundary_op
   for (int d = 0; d <= D; ++d) {
     issued += res_mt > 0 ? w4_res_loads(d, res_mt) : 0;  // first sub-step of d (in front of barrier d): never needed by a barrier
     if (d == D) break;
-    for (int i = 0; i < W4_TGW; ++i) { ++issued; if (d + PD <= D + 1) last_needed = issued; }
+    for (int i = 0; i < tgw; ++i) { ++issued; if (d + PD <= D + 1) last_needed = issued; }
     const int buf = w4_patch_buffer(d, PW, spread);
     for (int i = 0; i < w4_patch_pieces(d, PW, spread); ++i) { ++issued; if ((buf == 1 && D >= 3) || (buf == 0 && D >= 8)) last_needed = issued; }
   }

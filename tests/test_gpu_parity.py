@@ -115,7 +115,7 @@ def test_conflict_free_patch_image_and_4_wave_kernel_do_not_change_a_bit(state_d
     x = torch.rand(B, 3, H, W)
     outs, kernels = [], []
     cfgs = [dict(w4mt=7, w4cw=0), dict(w4mt=8), dict(w4mt=0, w4cw=0), dict(w4mt=6), dict(w4mt=5), dict(w4mt=4), dict(w4cw=2, w4cwf=3), dict(w4cw=4, w4cwf=3), dict(w4cw=16, w4cwf=3),
-            dict(w4cw=2, w4cwf=3, streams=2), dict(w4=0), dict(w4=0, skew=0)]
+            dict(w4cw=2, w4cwf=3, streams=2), dict(w8=1), dict(w4=0), dict(w4=0, skew=0)]
     for cfg in cfgs:
         opts = dict(streams=1, ksplit=0)                   # (split-K sends small launches to conv_stag: covered by test_split_k_small_batches)
         opts.update(cfg)
@@ -132,6 +132,7 @@ def test_conflict_free_patch_image_and_4_wave_kernel_do_not_change_a_bit(state_d
         assert kernels[0].count("conv_w4_kernel") == 9 and "[224 px tiles]" in kernels[0], kernels[0]
         assert kernels[1].count("[256 px tiles]") == 9, kernels[1]
         assert "conv_w4" not in kernels[-1] and kernels[-1].count("conv_stag_kernel<256x128>") == 9
+        assert kernels[10].count("conv_w8_kernel") == 9, kernels[10]
         walks = kernels[6].count("walk:")
         assert walks == (9 if B == 64 else 6 if B == 32 else 0), kernels[6]
         if B == 64:
