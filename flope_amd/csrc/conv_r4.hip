@@ -124,8 +124,20 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
   for (int ct = 0; ct < NT; ++ct) b4[ct] = *(const f32x4*)(p.bias + cb + (ct >> 1) * 32 + (ct & 1) * 4);
 
   // ---- tile walk: tile = image * tiles_per_image + band
+  // r04: workgroup b runs on XCD b % 8 (round-robin dispatch).  Each XCD owns one CONTIGUOUS eighth of the tiles and its G / 8
+  // workgroups walk it side by side (j, j + G / 8, ...), so the bands of an image -- which share two of their ten patch rows with
+  // each neighbour -- meet in one L2 (with tile = blockIdx.x + k G neighbours sat on different XCDs and every halo row came from the
+  // fabric twice: 1.31 - 1.33 x the algorithmic bytes, r03 counters), and the last, partly filled round is spread over all eight
+  // XCDs (xcd_remap's order left it on four of them: -1.3 % on the two-slice step).  Time: unchanged within noise (the launch is
+  // bound by the bytes it has to move), fabric traffic: down.
   const int G = gridDim.x;
-  int tile = blockIdx.x;
+  int tile = blockIdx.x, tstep = G, tend = p.total_tiles;
+  if ((G & 7) == 0) {
+    const int x = blockIdx.x & 7;
+    tile = (int)(((long)p.total_tiles * x) >> 3) + (blockIdx.x >> 3);
+    tend = (int)(((long)p.total_tiles * (x + 1)) >> 3);
+    tstep = G >> 3;
+  }
   auto tile_rows = [&](int tl, int& R0, int& m0) {
     const int b0 = tl / p.tiles_per_image, j0 = tl - b0 * p.tiles_per_image;
     R0 = b0 * p.Hip + j0 * 8;                              // first padded input row of the patch
@@ -207,24 +219,28 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
 #ifdef FLOPE_STAG_DBG
   // diagnostic build, dbg & 64: shader-clock stamps of this workgroup's THIRD tile (steady state), wave 0:
   // {tile start, before wait 1, after barrier 1, before wait 2, after barrier 2, loop end, epilogue end} + real time {start, end}
-  unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0}, st_r[2] = {0, 0};
+  unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_r[2] = {0, 0};   // 9: behind sub-step 8, 10: behind 12, 11: behind 0
   int st_it = 0;
 #define R4_STAMP(i_) do { if ((p.dbg & 64) && st_it == 2) { __builtin_amdgcn_sched_barrier(0); st[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define R4_STAMP(i_) do {} while (0)
 #endif
   for (;;) {
-    const bool has_next = tile + G < p.total_tiles;
+    const bool has_next = tile + tstep < tend;
     int nR0 = R0, nm0 = m0;
-    if (has_next) tile_rows(tile + G, nR0, nm0);
+    if (has_next) tile_rows(tile + tstep, nR0, nm0);
+#ifdef FLOPE_STAG_DBG      /* ablation (results wrong by construction), dbg & 1: the "next tile" burst re-reads this tile's own (L2-warm) patch */
+    const char* const n_patch_src = (p.dbg & 1) ? patch_src : (const char*)p.in + (size_t)nR0 * rowB;
+#else
     const char* const n_patch_src = (const char*)p.in + (size_t)nR0 * rowB;
+#endif
 
     R4_STAMP(0);
 #ifdef FLOPE_STAG_DBG
     if ((p.dbg & 64) && st_it == 2) st_r[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     const char* const rb = RES ? (const char*)p.res + (size_t)m0 * p.Wop * p.Cout * 2 : nullptr;
-    R4_SUB(0);
+    R4_SUB(0); R4_STAMP(11);
     R4_SUB(1); R4_SUB(2); R4_SUB(3); R4_SUB(4); R4_SUB(5); R4_SUB(6); R4_SUB(7);
     R4_STAMP(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's fragments of sub-step 8 (the last reads of buffer 0) are in registers
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
     if constexpr (RES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MT) : "memory"); else R4_WAIT_VM0();
     R4_BARRIER();
     R4_STAMP(2);
-    R4_SUB(8); R4_SUB(9); R4_SUB(10); R4_SUB(11); R4_SUB(12); R4_SUB(13); R4_SUB(14); R4_SUB(15); R4_SUB(16);
+    R4_SUB(8); R4_STAMP(9); R4_SUB(9); R4_SUB(10); R4_SUB(11); R4_SUB(12); R4_STAMP(10); R4_SUB(13); R4_SUB(14); R4_SUB(15); R4_SUB(16);
     R4_STAMP(3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... of sub-step 17 (the last reads of buffer 1)
     R4_WAIT_VM0();                                           // its pieces of the next tile's first half-chunk have landed
@@ -291,13 +307,13 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
       if (p.split_ws && wave == 0 && lane == 0) {
         unsigned long long* d_ = (unsigned long long*)p.split_ws + (size_t)blockIdx.x * 16;
         for (int i = 0; i < 7; ++i) d_[i] = st[i];
-        d_[7] = st_r[0]; d_[8] = st_r[1];
+        d_[7] = st_r[0]; d_[8] = st_r[1]; d_[9] = st[9]; d_[10] = st[10]; d_[11] = st[11];
       }
     }
     ++st_it;
 #endif
     if (!has_next) break;
-    tile += G;
+    tile += tstep;
     R0 = nR0; m0 = nm0; patch_src = n_patch_src;
   }
   R4_WAIT_VM0();

@@ -24,7 +24,7 @@ for kv in (sys.argv[2].split(",") if len(sys.argv) > 2 else []):
     k, v = kv.split("=")
     e.set_option(k, int(v))
 e.load_state_dict(sd)
-e.set_option("dbg", 64)
+e.set_option("dbg", 64 | int(os.environ.get("ABL", 0)))   # ABL=1: the next-tile burst re-reads the own (L2-warm) patch: timing only
 t0 = time.time()
 while time.time() - t0 < 2.5:
     for _ in range(50):
@@ -44,5 +44,7 @@ for i in range(4):
     d = r[ok]
     seg = [np.median(d[:, k + 1] - d[:, k]) for k in range(6)]
     clk = (d[:, 6] - d[:, 0]) / (d[:, 8] - d[:, 7]) * 0.1
+    if d[:, 9].any():
+        print(f"          sub 0 {np.median(d[:, 11] - d[:, 0]):.0f}  sub 1-7 {np.median(d[:, 1] - d[:, 11]):.0f} | sub 8 {np.median(d[:, 9] - d[:, 2]):.0f}  sub 9-12 {np.median(d[:, 10] - d[:, 9]):.0f}  sub 13-16 {np.median(d[:, 3] - d[:, 10]):.0f}")
     print(f"conv {i}: {int(ok.sum())} wg  " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, seg)) + f"  | tile {np.median(d[:, 6] - d[:, 0]):.0f}  clock {np.median(clk):.3f} GHz")
 e.close()
