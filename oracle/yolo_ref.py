@@ -35,18 +35,37 @@ NM = 32
 
 
 # ---- building blocks -----------------------------------------------------------------------------
-def conv(sd, p, x, k=1, s=1, act=True, groups=1):
-    """ultralytics ``Conv``: Conv2d(bias=False, padding=k//2) -> BatchNorm2d -> SiLU."""
+# forward_layers(..., emulate=torch.float16 / torch.bfloat16) restates WHERE the 16-bit device path (flope_amd/csrc/yolo*.hip) rounds:
+# BatchNorm folded into the conv weights in float32 and the folded weights stored in the 16-bit type (depthwise weights and every
+# bias stay float32), float32 accumulation, activation (+ residual) in float32, ONE rounding when a map is stored.  It pins the
+# bf16 mode far tighter than the float32 forward can (8 mantissa bits over 23 layers): tests/test_gpu_yolo.py.
+_EMU = None
+
+
+def _r(t):
+    return t if _EMU is None else t.to(_EMU).float()
+
+
+def conv(sd, p, x, k=1, s=1, act=True, groups=1, res=None):
+    """ultralytics ``Conv``: Conv2d(bias=False, padding=k//2) -> BatchNorm2d -> SiLU (+ res: a shortcut added behind the activation)."""
     w = sd[p + ".conv.weight"]
-    y = F.conv2d(x, w, None, stride=s, padding=w.shape[-1] // 2, groups=groups)
-    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"], sd[p + ".bn.bias"],
-                     training=False, eps=BN_EPS)
-    return F.silu(y) if act else y
+    if _EMU is None:
+        y = F.conv2d(x, w, None, stride=s, padding=w.shape[-1] // 2, groups=groups)
+        y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"], sd[p + ".bn.bias"],
+                         training=False, eps=BN_EPS)
+    else:
+        scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + BN_EPS)
+        wf = w * scale[:, None, None, None]
+        if groups == 1:
+            wf = _r(wf)
+        y = F.conv2d(x, wf, sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale, stride=s, padding=w.shape[-1] // 2, groups=groups)
+    y = F.silu(y) if act else y
+    return _r(y if res is None else y + res)
 
 
 def bottleneck(sd, p, x):
     """Bottleneck(c, c, shortcut=True, k=(3,3)): x + cv2(cv1(x))."""
-    return x + conv(sd, p + ".cv2", conv(sd, p + ".cv1", x))
+    return conv(sd, p + ".cv2", conv(sd, p + ".cv1", x), res=x)
 
 
 def c3k(sd, p, x):
@@ -88,7 +107,7 @@ def attention(sd, p, x):
     q, k, v = qkv.view(B, nh, kd * 2 + hd, N).split([kd, kd, hd], dim=2)
     attn = (q.transpose(-2, -1) @ k) * (kd ** -0.5)
     attn = attn.softmax(dim=-1)
-    y = (v @ attn.transpose(-2, -1)).view(B, C, H, W) + conv(sd, p + ".pe", v.reshape(B, C, H, W), act=False, groups=C)
+    y = _r(_r((v @ attn.transpose(-2, -1)).view(B, C, H, W)) + conv(sd, p + ".pe", v.reshape(B, C, H, W), act=False, groups=C))
     return conv(sd, p + ".proj", y, act=False)
 
 
@@ -98,21 +117,31 @@ def c2psa(sd, p, x):
     i = 0
     while f"{p}.m.{i}.attn.qkv.conv.weight" in sd:
         q = f"{p}.m.{i}"
-        b = b + attention(sd, q + ".attn", b)
-        b = b + conv(sd, q + ".ffn.1", conv(sd, q + ".ffn.0", b), act=False)
+        b = _r(b + attention(sd, q + ".attn", b))
+        b = conv(sd, q + ".ffn.1", conv(sd, q + ".ffn.0", b), act=False, res=b)
         i += 1
     return conv(sd, p + ".cv2", torch.cat([a, b], 1))
 
 
 def _plain(sd, p, x):
-    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"])
+    return F.conv2d(x, _r(sd[p + ".weight"]), sd[p + ".bias"])      # head rows: float32 outputs
 
 
-def forward_layers(sd: dict, x: torch.Tensor) -> dict:
-    """fp32 eval-mode forward of the 24-entry graph.  -> {layer index: output, 'box','cls','coef' per level, 'proto'}"""
+def forward_layers(sd: dict, x: torch.Tensor, emulate=None) -> dict:
+    """fp32 eval-mode forward of the 24-entry graph.  -> {layer index: output, 'box','cls','coef' per level, 'proto'}
+    emulate = a 16-bit torch dtype: with the device path's rounding points (see _EMU above)."""
+    global _EMU
+    _EMU = emulate
+    try:
+        return _forward_layers(sd, x)
+    finally:
+        _EMU = None
+
+
+def _forward_layers(sd: dict, x: torch.Tensor) -> dict:
     sd = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
     o = {}
-    o[0] = conv(sd, "model.0", x.float(), s=2)
+    o[0] = conv(sd, "model.0", _r(x.float()), s=2)
     o[1] = conv(sd, "model.1", o[0], s=2)
     o[2] = c3k2(sd, "model.2", o[1])
     o[3] = conv(sd, "model.3", o[2], s=2)
@@ -138,7 +167,7 @@ def forward_layers(sd: dict, x: torch.Tensor) -> dict:
         o[f"cls{i}"] = _plain(sd, f"{h}.cv3.{i}.2", t)
         o[f"coef{i}"] = _plain(sd, f"{h}.cv4.{i}.2", conv(sd, f"{h}.cv4.{i}.1", conv(sd, f"{h}.cv4.{i}.0", f)))
     t = conv(sd, h + ".proto.cv1", o[16])
-    t = F.conv_transpose2d(t, sd[h + ".proto.upsample.weight"], sd[h + ".proto.upsample.bias"], stride=2)
+    t = _r(F.conv_transpose2d(t, _r(sd[h + ".proto.upsample.weight"]), sd[h + ".proto.upsample.bias"], stride=2))
     o["proto_up"] = t
     o["proto"] = conv(sd, h + ".proto.cv3", conv(sd, h + ".proto.cv2", t))
     return o

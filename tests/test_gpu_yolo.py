@@ -31,9 +31,13 @@ def _engine(ysd, H, W, imgsz, dtype="f16"):
     return y
 
 
-@pytest.mark.parametrize("H,W,imgsz,dtype,tol", [(1080, 1920, 1280, "f16", 1e-2), (360, 640, 640, "f16", 1e-2), (300, 500, 320, "f16", 1e-2),
-                                                 (250, 333, 640, "bf16", 8e-2)])
-def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol):
+@pytest.mark.parametrize("H,W,imgsz,dtype,tol,tol_emu", [(1080, 1920, 1280, "f16", 1e-2, None), (360, 640, 640, "f16", 1e-2, 4e-3), (300, 500, 320, "f16", 1e-2, None),
+                                                         (250, 333, 640, "bf16", None, 2e-2)])
+def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol, tol_emu):
+    """Every graph output and head row block against the float32 oracle (tol), and -- r04 -- against the oracle run WITH the device
+    path's rounding points (Y.forward_layers(..., emulate=dtype): folded weights and stored maps in the 16-bit type, float32
+    accumulation; tol_emu).  bf16 is held to the emulating oracle only: its 8 mantissa bits over 23 layers put the float32 forward
+    4e-2 away from ANY bf16 evaluation of this graph (the emulation itself sits there), which is what r02's 8e-2 band had measured."""
     from flope_amd.yolo_weights import synthetic_frame
     img = synthetic_frame(3, H, W)
     y = _engine(ysd, H, W, imgsz, dtype)
@@ -43,20 +47,25 @@ def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol):
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     got_in = y.read_tensor("input").cpu()
     assert torch.equal(got_in[:3], x[0].to(tdt).float()) and not got_in[3:].any()      # letterbox + BGR->RGB + /255: exact
-    o = Y.forward_layers(ysd, x)
-    worst = [0.0, 0.0]
-    for name in LAYERS:
-        got = y.read_tensor(name).cpu()
-        ref = o[int(name)][0]
-        assert got.shape == ref.shape, name
-        worst[0] = max(worst[0], _rel(got, ref))
-        assert _rel(got, ref) <= tol, (name, _rel(got, ref))
-    for name in ["proto_up", "proto"] + [f"{k}{i}" for i in range(3) for k in ("box", "cls", "coef")]:
-        got, ref = y.read_tensor(name).cpu(), o[name][0]
-        assert got.shape == ref.shape, name
-        worst[1] = max(worst[1], _rel(got, ref))
-        assert _rel(got, ref) <= 2 * tol, (name, _rel(got, ref))
-    print(f"detector {dtype} {H}x{W}/{imgsz}: worst rel-L2 of a graph output {worst[0]:.2e}, of a head row block {worst[1]:.2e}")
+    refs = []
+    if tol is not None:
+        refs.append(("float32 oracle", Y.forward_layers(ysd, x), tol))
+    if tol_emu is not None:
+        refs.append((f"{dtype}-emulating oracle", Y.forward_layers(ysd, x, emulate=tdt), tol_emu))
+    for tag, o, t in refs:
+        worst = [0.0, 0.0]
+        for name in LAYERS:
+            got = y.read_tensor(name).cpu()
+            ref = o[int(name)][0]
+            assert got.shape == ref.shape, name
+            worst[0] = max(worst[0], _rel(got, ref))
+            assert _rel(got, ref) <= t, (tag, name, _rel(got, ref))
+        for name in ["proto_up", "proto"] + [f"{k}{i}" for i in range(3) for k in ("box", "cls", "coef")]:
+            got, ref = y.read_tensor(name).cpu(), o[name][0]
+            assert got.shape == ref.shape, name
+            worst[1] = max(worst[1], _rel(got, ref))
+            assert _rel(got, ref) <= 2 * t, (tag, name, _rel(got, ref))
+        print(f"detector {dtype} {H}x{W}/{imgsz} vs {tag}: worst rel-L2 of a graph output {worst[0]:.2e}, of a head row block {worst[1]:.2e}")
     y.close()
 
 
