@@ -31,8 +31,8 @@ def _engine(ysd, H, W, imgsz, dtype="f16"):
     return y
 
 
-@pytest.mark.parametrize("H,W,imgsz,dtype,tol,tol_emu", [(1080, 1920, 1280, "f16", 1e-2, None), (360, 640, 640, "f16", 1e-2, 4e-3), (300, 500, 320, "f16", 1e-2, None),
-                                                         (250, 333, 640, "bf16", None, 2e-2)])
+@pytest.mark.parametrize("H,W,imgsz,dtype,tol,tol_emu", [(1080, 1920, 1280, "f16", 5e-3, None), (360, 640, 640, "f16", 5e-3, 3e-3), (300, 500, 320, "f16", 5e-3, None),
+                                                         (250, 333, 640, "bf16", None, 1.5e-2)])     # measured (r04): 2.2e-3 / 2.0e-3, 1.4e-3 / 1.6e-3 / 1.2e-2
 def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol, tol_emu):
     """Every graph output and head row block against the float32 oracle (tol), and -- r04 -- against the oracle run WITH the device
     path's rounding points (Y.forward_layers(..., emulate=dtype): folded weights and stored maps in the 16-bit type, float32
