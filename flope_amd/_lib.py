@@ -38,6 +38,7 @@ SIGNATURES = {
     "flope_read_stage": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int64), _P]),
     "flope_set_option": (_I, [_P, C.c_char_p, _I]),
     "flope_debug_read_ws": (_I, [_P, _P, C.c_size_t, C.c_size_t]),
+    "flope_debug_pk16": (_I, [_I, _I, _P, _P, _I, _P]),
     "flope_forward_flops": (_D, [_P, _I]),
     "flope_forward_launches": (_I, [_P]),
     "flope_profile_read": (_I, [_P, C.POINTER(_F), _I]),

@@ -4,6 +4,7 @@
 // One thread = one (pixel, 4 consecutive output channels); threads of a wave share a
 // pixel neighbourhood so activation loads broadcast and weight loads coalesce
 // ([ky][kx][ci][cout] layout).
+#include "../../include/flope_amd.h"
 #include "common.h"
 
 __global__ __launch_bounds__(256) void naive_conv_kernel(const NaiveConvP p) {
@@ -43,4 +44,26 @@ extern "C" int flope_naive_conv_launch(const NaiveConvP* p, void* stream) {
   const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   hipLaunchKernelGGL(naive_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
+}
+
+// Developer aid: the packed 16-bit epilogue helpers of common.h on caller-supplied bit patterns, so that a test can run
+// the DEVICE code over every pattern.  which: 0 pk_out16<bf16>(w, relu), 1 pk_out16<f16>(w, relu), 2 pk_relu16<bf16>(w), 3 pk_relu16<f16>(w),
+// 4 pk_max16_nonneg(w, w2) (w2 = the next input word, cyclically)
+__global__ void pk16_probe_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n, int which, int relu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned w = in[i];
+  unsigned r;
+  if (which == 0) r = pk_out16<bf16_t>(w, relu != 0);
+  else if (which == 1) r = pk_out16<f16_t>(w, relu != 0);
+  else if (which == 2) r = pk_relu16<bf16_t>(w);
+  else if (which == 3) r = pk_relu16<f16_t>(w);
+  else r = pk_max16_nonneg(w, in[i + 1 < n ? i + 1 : 0]);
+  out[i] = r;
+}
+
+extern "C" int flope_debug_pk16(int which, int relu, const void* in_dev, void* out_dev, int n, void* stream) {
+  if (!in_dev || !out_dev || n < 1 || which < 0 || which > 4) return FLOPE_EINVAL;
+  hipLaunchKernelGGL(pk16_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned*)in_dev, (unsigned*)out_dev, n, which, relu);
+  return hipGetLastError() == hipSuccess ? FLOPE_OK : FLOPE_EHIP;
 }

@@ -158,6 +158,10 @@ int flope_set_option(flope_handle h, const char* name, int value);
  * the last forward left in the split-K workspace at byte offset i * 1048576 ({clk0, clk1, rt0, rt1} uint64 per workgroup and
  * wave group; per-double-step stamps 64 KB further with "dbg" = 128) -> host memory.  A production build leaves the workspace untouched. */
 int flope_debug_read_ws(flope_handle h, void* dst_host, size_t offset, size_t bytes);
+/* developer aid: the packed 16-bit epilogue helpers of csrc/common.h applied to n caller-supplied 32-bit words on the device
+ * (which: 0 pk_out16<bf16>, 1 pk_out16<f16>, 2 pk_relu16<bf16>, 3 pk_relu16<f16>, 4 pk_max16_nonneg(w[i], w[i+1])) -- lets a test
+ * run the device code of every conv / stem epilogue over all 65,536 patterns (tests/test_gpu_parity.py). */
+int flope_debug_pk16(int which, int relu, const void* in_dev, void* out_dev, int n, void* stream);
 /* algorithmic FLOPs of one forward for `batch` crops (2*MAC, convs + 2 FCs) */
 double flope_forward_flops(flope_handle h, int batch);
 /* number of kernel launches flope_forward enqueues */

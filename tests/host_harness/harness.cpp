@@ -64,14 +64,19 @@ void hh_pack_stem(const float* w, int dtype, uint16_t* dst) {
 //   formula  0: w4_wait_n (what the kernel uses);  1: r03's closed form;  2: the form r03 replaced (one burst too lax at barriers 3
 //            and 8 of a 5-deep ring) -- 1 and 2 only describe spread <= 1, boundary = res = 0
 // Returns 0 when every read is covered, else a positive code; msg names the first violation.
+// tgw: LDS-DMA pieces per wave and double tile -- 4 = conv_w4 (four waves), 2 = conv_w8 (eight waves, pw = PT pieces per burst)
+extern "C" int flope_host_w4_schedule_check_tgw(int nbd, int pw, int spread, int mt, int boundary, int res, int formula, int tgw, char* msg, int msg_cap);
 extern "C" int flope_host_w4_schedule_check(int nbd, int pw, int spread, int mt, int boundary, int res, int formula, char* msg, int msg_cap) {
+  return flope_host_w4_schedule_check_tgw(nbd, pw, spread, mt, boundary, res, formula, W4_TGW, msg, msg_cap);
+}
+extern "C" int flope_host_w4_schedule_check_tgw(int nbd, int pw, int spread, int mt, int boundary, int res, int formula, int tgw, char* msg, int msg_cap) {
   struct Op { int kind, a, b; };                         // kind 0: double tile a (absolute index, body * 9 + k) piece b; 1: patch buffer a, read in body b; 2: store; 3: residual load
   auto say = [&](const char* fmt, int x, int y, int z) { if (msg && msg_cap > 0) snprintf(msg, msg_cap, fmt, x, y, z); };
-  if (nbd < 3 || nbd > 5 || pw < 2 || mt < 4 || mt > 8) { say("bad arguments", 0, 0, 0); return 100; }
+  if (nbd < 3 || nbd > 5 || pw < 2 || mt < 4 || mt > 8 || tgw < 1 || tgw > 8 || (formula != 0 && tgw != W4_TGW)) { say("bad arguments", 0, 0, 0); return 100; }
   const int PD = nbd - 1;
   std::vector<Op> q;                                      // this wave's memory operations in issue order
   auto issue_second = [&](int body, int d) {              // second sub-step of double step d of `body` (behind its barrier d)
-    for (int i = 0; i < W4_TGW; ++i) q.push_back({0, body * 9 + d + PD, i});
+    for (int i = 0; i < tgw; ++i) q.push_back({0, body * 9 + d + PD, i});
     const int n = w4_patch_pieces(d, pw, spread), buf = w4_patch_buffer(d, pw, spread);
     for (int i = 0; i < n; ++i) q.push_back({1, buf, buf == 1 ? body : body + 1});
   };
@@ -95,7 +100,7 @@ extern "C" int flope_host_w4_schedule_check(int nbd, int pw, int spread, int mt,
     if (res) for (int i = 0; i < w4_res_loads(D, mt); ++i) q.push_back({3, 0, 0});   // first sub-step of D
     // the wait in front of barrier D
     int N;
-    if (formula == 0) N = w4_wait_n(D, PD, pw, spread, boundary ? 2 * mt : 0, res ? mt : 0);
+    if (formula == 0) N = w4_wait_n(D, PD, pw, spread, boundary ? 2 * mt : 0, res ? mt : 0, tgw);
     else if (formula == 1) N = w4_wait_n_r03(D, PD, pw);
     else N = w4_wait_n_r03_lax(D, PD, pw);
     const int landed = (int)q.size() - N;                 // operations 0 .. landed - 1 are complete in this wave (every wave runs the same stream)
@@ -103,7 +108,7 @@ extern "C" int flope_host_w4_schedule_check(int nbd, int pw, int spread, int mt,
       int seen = 0;
       for (int i = 0; i < (int)q.size(); ++i)
         if (q[i].kind == kind && q[i].a == a && (kind == 0 || q[i].b == b)) { ++seen; if (i >= landed) return false; }
-      return seen == (kind == 0 ? W4_TGW : pw);
+      return seen == (kind == 0 ? tgw : pw);
     };
     // reads behind barrier D (second sub-step of D, first sub-step of D + 1): double tile D + 1; fragments of sub-steps 2 D + 2 and
     // 2 D + 3 from patch buffer (sub-step / 9) -- sub-step >= 18 is the next body's buffer 0

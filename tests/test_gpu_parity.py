@@ -168,6 +168,57 @@ def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg
     e.close()
 
 
+def test_packed_16bit_epilogue_helpers_on_every_bit_pattern():
+    """csrc/common.h: pk_out16 (every conv epilogue: optional ReLU as a signed-integer max, float16 saturation at +-65504), pk_relu16
+    (stem: ReLU + saturation as two integer instructions) and pk_max16_nonneg (max-pool on non-negative values as an unsigned
+    integer max) -- the DEVICE code over all 65,536 patterns of both halves of a packed word, against their float
+    statements in numpy."""
+    import ctypes as C
+    from flope_amd import _lib
+    lib = _lib.load()
+    lo = np.arange(65536, dtype=np.uint32)
+    words = torch.from_numpy((lo | (((lo * 40503 + 12345) & 0xffff) << 16)).astype(np.int64)).to(torch.int32).cuda()     # every pattern in the low half, a permutation of them in the high half
+    out = torch.empty_like(words)
+
+    def run(which, relu):
+        rc = lib.flope_debug_pk16(which, relu, C.c_void_p(words.data_ptr()), C.c_void_p(out.data_ptr()), words.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint32).copy()
+
+    w = words.cpu().numpy().view(np.uint32)
+    halves = lambda a: np.stack([a & 0xffff, a >> 16]).astype(np.uint16)
+    hw = halves(w)
+    # float16
+    x = hw.view(np.float16).astype(np.float32)
+    finite = np.isfinite(x)
+    sat = lambda v: np.clip(v, -65504.0, 65504.0).astype(np.float16).view(np.uint16)
+    got = halves(run(1, 0))
+    assert np.array_equal(got[finite], hw[finite])                                    # identity on finite values (they are all within +-65504)
+    inf = np.isinf(x)
+    assert np.array_equal(got[inf], sat(x)[inf])                                      # +-inf saturate
+    got_r = halves(run(1, 1))
+    ref_r = sat(np.maximum(np.nan_to_num(x, nan=0.0), 0.0))
+    pos_nan = np.isnan(x) & (hw < 0x8000)
+    ok = ~np.isnan(x)
+    assert np.array_equal(got_r[ok], ref_r[ok]) and (got_r[pos_nan] == 0x7BFF).all()  # ReLU + saturation; a positive NaN leaves as 65504, a negative one as 0
+    assert (got_r[np.isnan(x) & (hw >= 0x8000)] == 0).all()
+    assert np.array_equal(halves(run(3, 0)), got_r)                                   # the stem's integer form: the same bits for EVERY pattern
+    # bfloat16: ReLU or identity, no saturation
+    assert np.array_equal(run(0, 0), w)
+    got_b = halves(run(0, 1))
+    assert np.array_equal(got_b, np.where(hw >= 0x8000, 0, hw).astype(np.uint16))
+    assert np.array_equal(halves(run(2, 0)), got_b)
+    # max of non-negative 16-bit floats = unsigned integer max (the pool works on post-ReLU values)
+    nn = torch.from_numpy(((lo & 0x7fff) | ((((lo * 40503 + 12345) & 0x7fff)) << 16)).astype(np.int64)).to(torch.int32).cuda()
+    words.copy_(nn)
+    a = halves(words.cpu().numpy().view(np.uint32)); b = np.roll(a, -1, axis=1)
+    fa, fb = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
+    both = ~np.isnan(fa) & ~np.isnan(fb)
+    got_m = halves(run(4, 0))
+    assert np.array_equal(got_m.view(np.float16).astype(np.float32)[both], np.maximum(fa, fb)[both])
+
+
 def test_reference_true_shape_512(state_dict):
     torch.manual_seed(12)
     x = torch.rand(2, 3, 512, 512)
