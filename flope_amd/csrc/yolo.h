@@ -32,6 +32,7 @@ struct YConvP {
   // [channel block of 16 nt rows][k16 step][channel tile][lane = kq * 16 + row][4 k] (k = 16 step + 4 kq + element), rows permuted
   // as in the 16-bit image; bias permuted the same way; k16 steps = ceil(k k Cin / 16)
   const void* w32m; const float* bias32m; int k16steps, nt32m;
+  unsigned wo_mg, wo_sh;                     // n / Wo as multiply-shift (the pixel decode of the small-map kernels)
 };
 
 struct YDwP {            // depthwise 3x3, stride 1, pad 1 (+ folded BN) (+ SiLU) (+ add)

@@ -22,7 +22,10 @@
 
 namespace {
 
-__device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+// SiLU on the 16-bit paths: v * rcp(1 + exp2(-v log2 e)) -- v_exp_f32 and v_rcp_f32 are good to ~1 ulp of float32, far inside the
+// rounding of the 16-bit store behind it, and 5 instructions instead of the ~16 of an IEEE division (r04 stamps: the activation math
+// was ~2 k of a small-map conv's 5.3 k in-kernel cycles... per value and lane, with one wave per SIMD).  (The strict float32 mode has its own kernels.)
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 template <typename T> __device__ __forceinline__ float ld16(const void* p) { return to_f32<T>(*(const T*)p); }
 
@@ -66,8 +69,17 @@ __device__ __forceinline__ void yconv_epilogue(const YConvP& p, const int nblk, 
     if (full) {
       if (p.res) {
         const char* r = (const char*)p.res + ((size_t)m * p.ldr + ch0) * 2;
+        if (NT >= 2 && (p.ldr & 7) == 0 && ((size_t)p.res & 15) == 0 && ((nblk * CB) & 7) == 0) {     // 16-byte aligned rows (wave-uniform): vector loads
 #pragma unroll
-        for (int i = 0; i < 4 * NT; ++i) v[i] += ld16<T>(r + i * 2);
+          for (int i = 0; i < NT / 2; ++i) {
+            const u32x4 rv = *(const u32x4*)(r + i * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[i * 8 + q * 2] += unpack_lo<T>(rv[q]); v[i * 8 + q * 2 + 1] += unpack_hi<T>(rv[q]); }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4 * NT; ++i) v[i] += ld16<T>(r + i * 2);
+        }
       }
       unsigned w[2 * NT];
 #pragma unroll
@@ -96,16 +108,97 @@ __device__ __forceinline__ void yconv_epilogue(const YConvP& p, const int nblk, 
 // Every variant keeps PD = 4 K steps of operand fragments in flight (the first version prefetched one step: 0.7 us per
 // step on the 23 x 40 maps, 50 us for a 72-step layer).
 // `red`: the workgroup's LDS scratch for the SPLITK combine, 3 * 2 * NT * 4 * 64 floats (24 KB at NT = 4).
+#ifdef FLOPE_STAG_DBG
+// diagnostic build: shader-clock stamps of workgroup (0, 0), wave 0 of every yconv_body launch, 8 words per launch in launch order
+// {entry, loads issued, K loop done, split-K combined, epilogue issued, realtime entry, realtime exit, M}; flope_ydbg_read
+__device__ unsigned long long g_ydbg[8 * 512];
+__device__ unsigned g_ydbg_n;
+#define YDBG_STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); yst[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define YDBG_STAMP(i_) do {} while (0)
+#endif
+
+// One (pixel tile, channel tile) unit of an epilogue: this lane's 4 channels ch .. ch + 3 of pixel m.  Element for element the
+// arithmetic of yconv_epilogue (activation, shortcut added behind it, one rounding): split-K hands a workgroup's units out to
+// its four waves (yconv_body) instead of leaving all of them to wave 0.
+template <typename T, int NT>
+__device__ __forceinline__ void yconv_epilogue_unit(const YConvP& p, const int nblk, const int g, const int m, const int ct, const f32x4 a) {
+  constexpr int CB = 16 * NT;
+  const int ch = nblk * CB + g * 4 * NT + ct * 4;
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = p.act ? silu(a[q]) : a[q];
+  if (p.out_mode == 1) {
+    float* o = (float*)p.out + (size_t)m * p.ldo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ch + q < p.Cout) o[ch + q] = v[q];
+    return;
+  }
+  size_t opix;
+  int och = ch;
+  if (p.out_mode == 2) {
+    const int quad = (nblk * CB) / p.dc;
+    const int oy = fastdiv(m, p.wo_mg, p.wo_sh), ox = m - oy * p.Wo;
+    opix = (size_t)(2 * oy + (quad >> 1)) * (2 * p.Wo) + 2 * ox + (quad & 1);
+    och = ch - quad * p.dc;
+  } else {
+    opix = (size_t)m;
+  }
+  char* o = (char*)p.out + (opix * p.ldo + och) * 2;
+  // (whole-lane-run criterion of yconv_epilogue: the run's last channels decide, so that both forms take the same path per element)
+  const bool full = p.out_mode == 2 || nblk * CB + g * 4 * NT + 4 * NT <= p.Cout;
+  if (full) {
+    if (p.res) {
+      const char* r = (const char*)p.res + ((size_t)m * p.ldr + ch) * 2;
+      if ((p.ldr & 3) == 0 && ((size_t)p.res & 7) == 0) {
+        const u32x2 rv = *(const u32x2*)r;
+        v[0] += unpack_lo<T>(rv[0]); v[1] += unpack_hi<T>(rv[0]); v[2] += unpack_lo<T>(rv[1]); v[3] += unpack_hi<T>(rv[1]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += ld16<T>(r + q * 2);
+      }
+    }
+    const unsigned w0 = pk_out16<T>(pack2<T>(v[0], v[1]), false), w1 = pk_out16<T>(pack2<T>(v[2], v[3]), false);
+    if ((p.ldo & 3) == 0 && ((size_t)p.out & 7) == 0 && (och & 3) == 0) *(u32x2*)o = u32x2{w0, w1};
+    else { *(unsigned short*)(o) = (unsigned short)(w0 & 0xffffu); *(unsigned short*)(o + 2) = (unsigned short)(w0 >> 16);
+           *(unsigned short*)(o + 4) = (unsigned short)(w1 & 0xffffu); *(unsigned short*)(o + 6) = (unsigned short)(w1 >> 16); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ch + q < p.Cout) {
+        float x = v[q];
+        if (p.res) x += ld16<T>((const char*)p.res + ((size_t)m * p.ldr + ch + q) * 2);
+        *(T*)(o + q * 2) = from_f32<T>(x);
+      }
+  }
+}
+
 template <typename T, int NT, bool K3, bool SPLITK>
 __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const int by, float* const red) {
   typedef typename Elem<T>::frag frag;
+#ifdef FLOPE_STAG_DBG
+  unsigned long long yst[5] = {0, 0, 0, 0, 0};
+  const unsigned long long yrt0 = __builtin_amdgcn_s_memrealtime();
+  YDBG_STAMP(0);
+#endif
   constexpr int MTW = 2, CB = 16 * NT, PD = 4;       // pixel tiles per wave, channels per block, pipeline depth
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int m_base = SPLITK ? bx * (16 * MTW) : (bx * 4 + wave) * (16 * MTW);
   if (!SPLITK && m_base >= p.M) return;
   const int nblk = by;
   const int pad = K3 ? 1 : 0;
+  // r04 (in-kernel stamps, tools/clock_probe_yolo.py: a 1x1 conv on the 23 x 40 map spent 4 k cycles before its first load and 4 k in
+  // the epilogue of ONE wave, of 11.5 k in all): the bias goes into the first MFMA as its C operand (no wait for it in front of the
+  // operand loads), the pixel decode is a multiply-shift, only the K steps a wave has are prefetched, and the split-K epilogue is
+  // spread over the four waves.
+  f32x4 bv[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    bv[ct] = *(const f32x4*)(p.bias + nblk * CB + ct * 16 + g * 4);              // bias is stored in packed-row order
+    if (SPLITK && wave != 0) bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   int iy0[MTW], ix0[MTW];
   bool pv[MTW];
 #pragma unroll
@@ -113,7 +206,7 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
     const int m = m_base + pt * 16 + c16;
     pv[pt] = m < p.M;
     const int mm = pv[pt] ? m : p.M - 1;
-    const int oy = mm / p.Wo, ox = mm - oy * p.Wo;
+    const int oy = fastdiv(mm, p.wo_mg, p.wo_sh), ox = mm - oy * p.Wo;
     iy0[pt] = oy * p.stride - pad;
     ix0[pt] = ox * p.stride - pad;
   }
@@ -124,13 +217,6 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
   const char* const zero = (const char*)p.zero;
   const int ks0 = SPLITK ? (wave * p.ksteps) >> 2 : 0, ks1 = SPLITK ? ((wave + 1) * p.ksteps) >> 2 : p.ksteps;
   f32x4 acc[MTW][NT];
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-    f32x4 b = *(const f32x4*)(p.bias + nblk * CB + ct * 16 + g * 4);           // bias is stored in packed-row order
-    if (SPLITK && wave != 0) b = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pt = 0; pt < MTW; ++pt) acc[pt][ct] = b;
-  }
   auto load_step = [&](int ks, frag (&wf)[NT], frag (&xf)[MTW]) {
     const int kg = ks * 4 + g;
     int c8, ky = 0, kx = 0;
@@ -155,14 +241,30 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
       xf[pt] = *(const frag*)a;
     }
   };
-  // software pipeline, PD steps deep: loads are unconditional (steps past the end re-read the last one) so that the
-  // compiler's counted s_waitcnt vmcnt(N) never degenerates into a full drain at a control-flow join
+  // software pipeline, PD steps deep; every condition below is wave-uniform
   frag wf[PD][NT], xf[PD][MTW];
-  const int klast = ks1 - 1;
   if (ks0 < ks1) {
 #pragma unroll
-    for (int s_ = 0; s_ < PD; ++s_) load_step(min(ks0 + s_, klast), wf[s_], xf[s_]);
-    for (int ks = ks0; ks < ks1; ks += PD) {
+    for (int s_ = 0; s_ < PD; ++s_)
+      if (s_ == 0 || ks0 + s_ < ks1) load_step(ks0 + s_, wf[s_], xf[s_]);      // (a wave of a split-K 1x1 conv often has two steps)
+    YDBG_STAMP(1);
+    // first step: C = bias
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[0][ct], xf[0][pt], bv[ct]);
+    if (ks0 + PD < ks1) load_step(ks0 + PD, wf[0], xf[0]);
+#pragma unroll
+    for (int s_ = 1; s_ < PD; ++s_) {
+      if (ks0 + s_ < ks1) {
+#pragma unroll
+        for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[s_][ct], xf[s_][pt], acc[pt][ct]);
+      }
+      if (ks0 + s_ + PD < ks1) load_step(ks0 + s_ + PD, wf[s_], xf[s_]);
+    }
+    for (int ks = ks0 + PD; ks < ks1; ks += PD) {
 #pragma unroll
       for (int s_ = 0; s_ < PD; ++s_) {
         if (ks + s_ < ks1) {
@@ -171,35 +273,72 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[s_][ct], xf[s_][pt], acc[pt][ct]);
         }
-        load_step(min(ks + s_ + PD, klast), wf[s_], xf[s_]);
+        if (ks + s_ + PD < ks1) load_step(ks + s_ + PD, wf[s_], xf[s_]);
       }
     }
+  } else {
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = bv[ct];
   }
-  if constexpr (SPLITK) {
-    constexpr int RW = MTW * NT * 4;
-    if (wave != 0) {
-#pragma unroll
-      for (int pt = 0; pt < MTW; ++pt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) red[((wave - 1) * RW + (pt * NT + ct) * 4 + q) * 64 + lane] = acc[pt][ct][q];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
-#pragma unroll
-      for (int pt = 0; pt < MTW; ++pt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[pt][ct][q] += red[(w * RW + (pt * NT + ct) * 4 + q) * 64 + lane];
-  }
+#ifdef FLOPE_STAG_DBG
+  { float keep_ = acc[0][0][0]; asm volatile("" : "+v"(keep_)); }
+  YDBG_STAMP(2);
+#endif
   int mm[MTW];
 #pragma unroll
   for (int pt = 0; pt < MTW; ++pt) mm[pt] = m_base + pt * 16 + c16;
-  yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
+  if constexpr (SPLITK) {
+    // unit u = pt * NT + ct belongs to wave u & 3 (NT = 4: channel tile w of both pixel tiles; NT = 2: one unit each; NT = 1: waves 0
+    // and 1).  A wave parks the units it does not own ([source index among the three others][unit][q][lane]), the owner adds the
+    // four partial sums in WAVE order -- ((P0 + P1) + P2) + P3, the order of the one-wave combine -- and runs the unit's epilogue.
+    constexpr int RW = MTW * NT * 4;
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const int own = (pt * NT + ct) & 3;
+        if (own != wave) {
+          const int si = wave < own ? wave : wave - 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) red[(si * RW + (pt * NT + ct) * 4 + q) * 64 + lane] = acc[pt][ct][q];
+        }
+      }
+    __syncthreads();
+    YDBG_STAMP(3);
+#pragma unroll
+    for (int pt = 0; pt < MTW; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        if (((pt * NT + ct) & 3) != wave || !pv[pt]) continue;
+        f32x4 t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          f32x4 part;
+          if (s == wave) part = acc[pt][ct];
+          else {
+            const int si = s < wave ? s : s - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[q] = red[(si * RW + (pt * NT + ct) * 4 + q) * 64 + lane];
+          }
+          if (s == 0) t = part;
+          else { t[0] += part[0]; t[1] += part[1]; t[2] += part[2]; t[3] += part[3]; }
+        }
+        yconv_epilogue_unit<T, NT>(p, nblk, g, mm[pt], ct, t);
+      }
+  } else {
+    YDBG_STAMP(3);
+    yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
+  }
+#ifdef FLOPE_STAG_DBG
+  YDBG_STAMP(4);
+  if (bx == 0 && by == 0 && threadIdx.x == 0) {
+    const unsigned slot = atomicAdd(&g_ydbg_n, 1u) & 511u;
+    for (int i = 0; i < 5; ++i) g_ydbg[slot * 8 + i] = yst[i];
+    g_ydbg[slot * 8 + 5] = yrt0; g_ydbg[slot * 8 + 6] = __builtin_amdgcn_s_memrealtime(); g_ydbg[slot * 8 + 7] = (unsigned long long)p.M | ((unsigned long long)p.ksteps << 32);
+  }
+#endif
 }
 
 template <typename T, int NT, int MTW>
@@ -1521,3 +1660,16 @@ extern "C" int flope_ymask_launch(const YMaskP* p, int dtype, void* stream) {
   hipLaunchKernelGGL(ymask_merge_kernel, dim3((p->ih * p->iw + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p);
   return (int)hipGetLastError();
 }
+
+#ifdef FLOPE_STAG_DBG
+// diagnostic build: copies the stamp records of the last launches to host memory and resets the counter; returns the count
+extern "C" int flope_ydbg_read(unsigned long long* dst_host, int cap_records) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ydbg_n), sizeof(n)) != hipSuccess) return -1;
+  const int m = (int)(n < 512u ? n : 512u) < cap_records ? (int)(n < 512u ? n : 512u) : cap_records;
+  if (m > 0 && hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_ydbg), (size_t)m * 64) != hipSuccess) return -1;
+  n = 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_ydbg_n), &n, sizeof(n));
+  return m;
+}
+#endif

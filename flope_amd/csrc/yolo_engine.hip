@@ -293,6 +293,7 @@ struct Builder {
     if (res) { c.res = vptr(*res); c.ldr = vld(*res); }
     c.zero = e->zero; c.k = k; c.stride = stride; c.act = act; c.cg = in.C / 8;
     fastdiv_magic((unsigned)c.cg, &c.cg_mg, &c.cg_sh);
+    fastdiv_magic((unsigned)Wo, &c.wo_mg, &c.wo_sh);
     c.out_mode = out_mode; c.dc = out_mode == 2 ? co / 4 : 0;
     e->flops += 2.0 * c.M * (double)rows * cin * k * k;
     op.reads.push_back(rng(in));
