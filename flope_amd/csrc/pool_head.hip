@@ -104,13 +104,21 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const void* in, float* out
         s1 += unpack_hi<T>(v);
       }
     } else {
-#pragma unroll 4
-      for (int i = pg; i < npx; i += 4) {
-        const int y = i / w, x = i - y * w;
-        const unsigned v = base[(size_t)((y + 1) * Wp + x + 1) * (C / 2)];
-        s0 += unpack_lo<T>(v);
-        s1 += unpack_hi<T>(v);
+      // r04 (the head is the step's exposed tail): the <= 16 pixels of this thread's group are loaded FIRST, their offsets stepped
+      // without a division, then added in the same order as before (bit-identical)
+      constexpr int NJ = 16;
+      unsigned v[NJ];
+      int x = pg % w, y = pg / w;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool in_ = pg + 4 * j < npx;
+        v[j] = in_ ? base[(size_t)((y + 1) * Wp + x + 1) * (C / 2)] : 0u;
+        x += 4;
+        while (x >= w) { x -= w; ++y; }
       }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (pg + 4 * j < npx) { s0 += unpack_lo<T>(v[j]); s1 += unpack_hi<T>(v[j]); }
     }
   }
   red[pg][cl * 2] = s0; red[pg][cl * 2 + 1] = s1;
@@ -198,15 +206,18 @@ __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ feat
 // its 64 lanes on 16 rows = 64 different cache lines (weights 2 KB apart, feature rows too) and the L1's tag rate, not bytes,
 // sets its 19 us.  Here W1 is pre-packed in A-fragment order [n tile][K / 32][2][lane][4] (a wave-load = one contiguous KiB)
 // and the workgroup's 32 feature rows are staged once into LDS (row pitch K + 4 floats: conflict-free ds_read_b128).
+// TI = image tiles of 16 per wave.  r04: 1 (was 2) -- a wave's 128 instead of 256 dependent-chain MFMAs (32 cycles of issue each) are
+// the kernel's latency, and twice the workgroups fill more of the chip; the K order per output is unchanged (bit-identical).
+template <int TI>
 __global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict__ feat, const float* __restrict__ W1p,
                                                          const float* __restrict__ b1, float* __restrict__ hidden,
                                                          int B, int K, int N) {
-  extern __shared__ __attribute__((aligned(16))) float sfeat[];           // [32][K + 4]
+  extern __shared__ __attribute__((aligned(16))) float sfeat[];           // [16 TI][K + 4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   const int g = lane >> 4, r16 = lane & 15;
   const int ntile = blockIdx.x * (nthr >> 6) + wave;        // 4 waves per workgroup, 1 for small batches (4x the workgroups)
   const int n0 = ntile * 16;
-  const int img0 = blockIdx.y * 32;
+  const int img0 = blockIdx.y * (16 * TI);
   const int KB = K >> 5, pitch = K + 4, k4 = K >> 2;
   const f32x4* wp = (const f32x4*)W1p + ((size_t)min(ntile, N / 16 - 1) * KB * 2) * 64 + lane;
 #ifndef FLOPE_FC1_WPD
@@ -216,24 +227,24 @@ __global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict
   f32x4 wa[WPD][2];
 #pragma unroll
   for (int d = 0; d < WPD; ++d) { const int kb = min(d, KB - 1); wa[d][0] = wp[(size_t)kb * 128]; wa[d][1] = wp[(size_t)kb * 128 + 64]; }
-  for (int i0 = tid; i0 < 32 * k4; i0 += 8 * nthr) {
+  for (int i0 = tid; i0 < 16 * TI * k4; i0 += 8 * nthr) {
     f32x4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = min(i0 + u * nthr, 32 * k4 - 1), row = i / k4, c = i - row * k4;
+      const int i = min(i0 + u * nthr, 16 * TI * k4 - 1), row = i / k4, c = i - row * k4;
       v[u] = *(const f32x4*)(feat + (size_t)min(img0 + row, B - 1) * K + 4 * c);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * nthr, row = i / k4, c = i - row * k4;
-      if (i < 32 * k4) *(f32x4*)(sfeat + row * pitch + 4 * c) = v[u];
+      if (i < 16 * TI * k4) *(f32x4*)(sfeat + row * pitch + 4 * c) = v[u];
     }
   }
   __syncthreads();
   if (n0 >= N) return;
-  f32x4 acc[2][2];                                          // [image tile][K parity]: 4 independent chains
+  f32x4 acc[TI][2];                                         // [image tile][K parity]: independent chains
 #pragma unroll
-  for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+  for (int t = 0; t < TI; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
   const float* f0p = sfeat + r16 * pitch + 4 * g;
   for (int kb0 = 0; kb0 < KB; kb0 += WPD) {
 #pragma unroll
@@ -243,13 +254,13 @@ __global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict
       const f32x4 a0 = wa[d][0], a1 = wa[d][1];
       const int nb = min(kb + WPD, KB - 1);
       wa[d][0] = wp[(size_t)nb * 128]; wa[d][1] = wp[(size_t)nb * 128 + 64];
-      f32x4 f0[2], f1[2];
+      f32x4 f0[TI], f1[TI];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { f0[t] = *(const f32x4*)(f0p + t * 16 * pitch + kb * 32); f1[t] = *(const f32x4*)(f0p + t * 16 * pitch + kb * 32 + 16); }
+      for (int t = 0; t < TI; ++t) { f0[t] = *(const f32x4*)(f0p + t * 16 * pitch + kb * 32); f1[t] = *(const f32x4*)(f0p + t * 16 * pitch + kb * 32 + 16); }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TI; ++t) {
           acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], f0[t][s], acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], f1[t][s], acc[t][1], 0, 0, 0);
         }
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256) void fc1_packed_kernel(const float* __restrict
   }
   const f32x4 bias = *(const f32x4*)(b1 + n0 + 4 * g);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < TI; ++t) {
     const int img = img0 + t * 16 + r16;
     if (img < B) {
       f32x4 o;
@@ -286,13 +297,11 @@ __global__ __launch_bounds__(256) void fc1_simple_kernel(const float* feat, cons
 extern "C" int flope_fc1_launch(const float* feat, const float* W1, const float* W1p, const float* b1, float* hidden, int B, int K,
                                 int N, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)32 * (K + 4) * sizeof(float);
-  if (W1p && K % 32 == 0 && N % 16 == 0 && lds <= 96 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)fc1_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; }
+  const size_t lds = (size_t)16 * (K + 4) * sizeof(float);  // 33 KB at K = 512: inside the default dynamic-LDS limit (no per-device attribute)
+  if (W1p && K % 32 == 0 && N % 16 == 0 && lds <= 64 * 1024) {
     const int waves = 4;                                    // (one wave per workgroup for small batches measured slower: 20.9 vs 19.0 us)
-    const dim3 grid((N / 16 + waves - 1) / waves, (B + 31) / 32);
-    hipLaunchKernelGGL(fc1_packed_kernel, grid, dim3(64 * waves), lds, st, feat, W1p, b1, hidden, B, K, N);
+    const dim3 grid((N / 16 + waves - 1) / waves, (B + 15) / 16);
+    hipLaunchKernelGGL(fc1_packed_kernel<1>, grid, dim3(64 * waves), lds, st, feat, W1p, b1, hidden, B, K, N);
   } else if (K % 32 == 0 && N % 16 == 0) {
     const dim3 grid((N / 16 + 3) / 4, (B + 31) / 32);
     hipLaunchKernelGGL(fc1_kernel, grid, dim3(256), 0, st, feat, W1, b1, hidden, B, K, N);
