@@ -420,6 +420,11 @@ __device__ __forceinline__ void yconv_tile_body(const YConvP& p, const int bx, c
       return;
     }
   }
+#ifdef FLOPE_STAG_DBG
+  unsigned long long yst[5] = {0, 0, 0, 0, 0};
+  const unsigned long long yrt0 = __builtin_amdgcn_s_memrealtime();
+  YDBG_STAMP(0);
+#endif
   frag wf[PD][NT];
 #pragma unroll
   for (int s_ = 0; s_ < PD; ++s_)
@@ -454,7 +459,9 @@ __device__ __forceinline__ void yconv_tile_body(const YConvP& p, const int bx, c
         if (dst[j] >= 0) *(u32x4*)(lds + dst[j]) = v[j];
     }
   }
+  YDBG_STAMP(1);
   __syncthreads();
+  YDBG_STAMP(2);
   // ---- K loop: B fragments from LDS (one step ahead), A fragments from global memory (PD steps ahead)
   const int prow = (wave * 2 * s) * PW + c16 * s;                       // patch pixel of (tile row 2w, column c16), tap (0, 0)
   auto xload = [&](int ks, frag (&xf)[MTW]) {
@@ -506,7 +513,20 @@ __device__ __forceinline__ void yconv_tile_body(const YConvP& p, const int bx, c
     pv[pt] = oy < p.Ho && ox < p.Wo;
     mm[pt] = oy * p.Wo + ox;
   }
+#ifdef FLOPE_STAG_DBG
+  { float keep_ = acc[0][0][0]; asm volatile("" : "+v"(keep_)); }
+  YDBG_STAMP(3);
+#endif
   yconv_epilogue<T, NT, MTW>(p, nblk, g, mm, pv, acc);
+#ifdef FLOPE_STAG_DBG
+  YDBG_STAMP(4);
+  if (bx == 0 && by == 0 && threadIdx.x == 0) {
+    const unsigned slot = atomicAdd(&g_ydbg_n, 1u) & 511u;
+    for (int i = 0; i < 5; ++i) g_ydbg[slot * 8 + i] = yst[i];
+    g_ydbg[slot * 8 + 5] = yrt0; g_ydbg[slot * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    g_ydbg[slot * 8 + 7] = (unsigned long long)p.M | ((unsigned long long)p.ksteps << 32) | (1ull << 63);      // bit 63: tile path
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -27,9 +27,10 @@ lib.flope_ydbg_read(buf.ctypes.data_as(C.c_void_p), 512)   # reset
 y.forward(img)
 n = lib.flope_ydbg_read(buf.ctypes.data_as(C.c_void_p), 512)
 r = buf[: n * 8].reshape(-1, 8).astype(np.int64)
-print(f"{n} yconv_body launches of one frame (one launch per op): cycles entry->loads issued | ->K loop done | ->combined | ->epilogue issued ; kernel-internal us, clock")
+print(f"{n} conv launches of one frame (one launch per op), workgroup (0,0): small-map kernel: cycles entry->loads issued | ->K loop done | ->combined | ->epilogue issued; tile kernel: entry->patch loads issued+written | ->barrier | ->K loop done | ->epilogue issued; in-kernel us, clock")
 for i, d in enumerate(r):
     rt = (d[6] - d[5]) * 0.01
     cyc = d[4] - d[0]
-    print(f"{i:3d} M={d[7] & 0xffffffff:6d} ksteps={d[7] >> 32:3d}  {d[1]-d[0]:6d} {d[2]-d[1]:6d} {d[3]-d[2]:6d} {d[4]-d[3]:6d}   {rt:6.2f} us  {cyc / max(rt, 1e-3) / 1e3:5.2f} GHz")
+    tile = "tile " if d[7] < 0 else "small"
+    print(f"{i:3d} {tile} M={d[7] & 0xffffffff:6d} ksteps={(d[7] >> 32) & 0x7fffffff:3d}  {d[1]-d[0]:6d} {d[2]-d[1]:6d} {d[3]-d[2]:6d} {d[4]-d[3]:6d}   {rt:6.2f} us  {cyc / max(rt, 1e-3) / 1e3:5.2f} GHz")
 y.close()
