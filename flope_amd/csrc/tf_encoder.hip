@@ -260,12 +260,27 @@ __global__ void tf_attn_generic(const T* qkv, T* out, int L, int d, int H) {
 //   weights: host-packed as the swizzled LDS image ([ntile][chunk][128 rows][128 B]) -> linear copy
 //   tokens : swizzle applied on the per-lane source address
 // LDS image: row r (128 B = 64 k), 16-byte slot j holds k-chunk j ^ ((r >> 1) & 7)  -> ds_read_b128 conflict-free.
+#ifdef FLOPE_STAG_DBG
+// diagnostic build: shader-clock stamps of workgroup 0, wave 0 of every tf_gemm_mfma launch {entry, first DMA issued, first chunk landed, K loop done,
+// epilogue issued, realtime entry, realtime exit, K | N << 32}; flope_tfdbg_read
+__device__ unsigned long long g_tfdbg[8 * 512];
+__device__ unsigned g_tfdbg_n;
+#define TFDBG_STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); tst[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TFDBG_STAMP(i_) do {} while (0)
+#endif
+
 template <typename T, bool RELU, bool RES>
 __global__ __launch_bounds__(256, 2) void tf_gemm_mfma(const T* __restrict__ X, const void* __restrict__ Wp,
                                                        const float* __restrict__ bias, const T* __restrict__ res,
                                                        T* __restrict__ Y, int K, int N) {
   typedef typename Elem<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][ W 16 KiB | X 16 KiB ]
+#ifdef FLOPE_STAG_DBG
+  unsigned long long tst[5] = {0, 0, 0, 0, 0};
+  const unsigned long long trt0 = __builtin_amdgcn_s_memrealtime();
+  TFDBG_STAMP(0);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int ntiles = N >> 7, mt = id / ntiles, nt = id - mt * ntiles, nch = K >> 6;
@@ -301,9 +316,13 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_mfma(const T* __restrict__ X, 
   } while (0)
 
   TF_ISSUE(0, 0);
+  TFDBG_STAMP(1);
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) { TF_ISSUE(c + 1, (c + 1) & 1); WAIT_VM(8); } else { WAIT_VM(0); }
     BLOCK_BARRIER();
+#ifdef FLOPE_STAG_DBG
+    if (c == 0) TFDBG_STAMP(2);
+#endif
     const char* bs = smem + (c & 1) * 32768;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -322,6 +341,10 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_mfma(const T* __restrict__ X, 
     BLOCK_BARRIER();
   }
 #undef TF_ISSUE
+#ifdef FLOPE_STAG_DBG
+  { float keep_ = acc[0][0][0]; asm volatile("" : "+v"(keep_)); }
+  TFDBG_STAMP(3);
+#endif
 
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt) {
@@ -350,6 +373,14 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_mfma(const T* __restrict__ X, 
     *(u32x4*)(Y + off) = o0;
     *(u32x4*)(Y + off + 8) = o1;
   }
+#ifdef FLOPE_STAG_DBG
+  TFDBG_STAMP(4);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned slot = atomicAdd(&g_tfdbg_n, 1u) & 511u;
+    for (int i = 0; i < 5; ++i) g_tfdbg[slot * 8 + i] = tst[i];
+    g_tfdbg[slot * 8 + 5] = trt0; g_tfdbg[slot * 8 + 6] = __builtin_amdgcn_s_memrealtime(); g_tfdbg[slot * 8 + 7] = (unsigned long long)K | ((unsigned long long)N << 32);
+  }
+#endif
 }
 
 // ---- MFMA attention, head_dim 64 ------------------------------------------------------------------------------
@@ -782,3 +813,15 @@ extern "C" double flope_tf_forward_flops(flope_tf_handle e, int batch, int seq_l
   mac += e->nl * (M * d * 3 * d + M * d * d + 2.0 * M * d * e->ff + 2.0 * M * seq_len * d);
   return 2.0 * mac;
 }
+
+#ifdef FLOPE_STAG_DBG
+extern "C" int flope_tfdbg_read(unsigned long long* dst_host, int cap_records) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tfdbg_n), sizeof(n)) != hipSuccess) return -1;
+  const int m0 = (int)(n < 512u ? n : 512u), m = m0 < cap_records ? m0 : cap_records;
+  if (m > 0 && hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_tfdbg), (size_t)m * 64) != hipSuccess) return -1;
+  n = 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_tfdbg_n), &n, sizeof(n));
+  return m;
+}
+#endif
