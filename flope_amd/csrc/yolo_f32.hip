@@ -473,7 +473,7 @@ __device__ __forceinline__ void y32m_conv_body(const YConvP& p, int bx, int by, 
     const int m = m0 + t * 16 + c16;
     pv[t] = m < p.M;
     const int mc = pv[t] ? m : p.M - 1;
-    oy[t] = mc / p.Wo; ox[t] = mc - oy[t] * p.Wo;
+    oy[t] = fastdiv(mc, p.wo_mg, p.wo_sh); ox[t] = mc - oy[t] * p.Wo;
   }
   f32x4m acc[MP][NT];
 #pragma unroll
@@ -538,58 +538,72 @@ __device__ __forceinline__ void y32m_conv_body(const YConvP& p, int bx, int by, 
     if (ks + 2 * U * kinc < nsteps) load_chunk(ks + 2 * U * kinc, xa, wa);
     mfma_chunk(ks + U * kinc, xb, wbf);
   }
-  if constexpr (SPLITK) {                                  // partial sums of waves 1..3 -> LDS, wave 0 adds them in wave order
-    if (wave > 0) {
-#pragma unroll
-      for (int t = 0; t < MP; ++t)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) *(f32x4m*)(red + ((((wave - 1) * MP + t) * NT + ct) * 64 + lane) * 4) = acc[t][ct];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
-#pragma unroll
-      for (int t = 0; t < MP; ++t)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-          const f32x4m r = *(const f32x4m*)(red + (((w * MP + t) * NT + ct) * 64 + lane) * 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[t][ct][q] += r[q];
-        }
-  }
-  // epilogue: lane (kq, c16) holds pixel c16 x rows blk * CB + kq * 4 NT + ct * 4 + q = 4 NT consecutive output rows
+  // epilogue of one (pixel tile t, channel tile ct) unit: lane (kq, c16) holds pixel c16 x rows blk * CB + kq * 4 NT + ct * 4 + q
   const int r0 = blk * CB + kq * 4 * NT;
-#pragma unroll
-  for (int t = 0; t < MP; ++t) {
-    if (!pv[t]) continue;
+  auto epilogue_unit = [&](int t, int ct, const f32x4m a) {
     const int m = m0 + t * 16 + c16;
-    float v[4 * NT];
+    float v[4];
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const float a = acc[t][ct][q]; v[ct * 4 + q] = p.act ? silu32(a) : a; }
+    for (int q = 0; q < 4; ++q) v[q] = p.act ? silu32(a[q]) : a[q];
     if (p.out_mode == 2) {                                 // ConvTranspose2d 2x2 s2: rows r0 .. lie in one (dy, dx) quadrant (dc % 16 == 0)
-      if (r0 >= rows) continue;
+      if (r0 >= rows) return;
       const int quad = r0 / p.dc, co = r0 - quad * p.dc;
       const size_t opix = (size_t)(2 * oy[t] + (quad >> 1)) * (2 * p.Wo) + 2 * ox[t] + (quad & 1);
       float* o = (float*)p.out + opix * p.ldo + co;
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) *(f32x4m*)(o + ct * 4) = f32x4m{v[ct * 4], v[ct * 4 + 1], v[ct * 4 + 2], v[ct * 4 + 3]};
+      *(f32x4m*)(o + ct * 4) = f32x4m{v[0], v[1], v[2], v[3]};
     } else {
       if (p.res) {
-        const float* rp = (const float*)p.res + (size_t)m * p.ldr + r0;
+        const float* rp = (const float*)p.res + (size_t)m * p.ldr + r0 + ct * 4;
 #pragma unroll
-        for (int i = 0; i < 4 * NT; ++i) if (r0 + i < rows) v[i] += rp[i];
+        for (int q = 0; q < 4; ++q) if (r0 + ct * 4 + q < rows) v[q] += rp[q];
       }
-      float* o = (float*)p.out + (size_t)m * p.ldo + r0;
+      float* o = (float*)p.out + (size_t)m * p.ldo + r0 + ct * 4;
       if (p.out_mode == 0 && r0 + 4 * NT <= rows) {        // map views: 16-byte aligned runs
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) *(f32x4m*)(o + ct * 4) = f32x4m{v[ct * 4], v[ct * 4 + 1], v[ct * 4 + 2], v[ct * 4 + 3]};
+        *(f32x4m*)o = f32x4m{v[0], v[1], v[2], v[3]};
       } else {                                             // prediction rows (odd pitch) and ragged channel counts
 #pragma unroll
-        for (int i = 0; i < 4 * NT; ++i) if (r0 + i < rows) o[i] = v[i];
+        for (int q = 0; q < 4; ++q) if (r0 + ct * 4 + q < rows) o[q] = v[q];
       }
+    }
+  };
+  if constexpr (SPLITK) {
+    // r04b: unit u = t * NT + ct belongs to wave u & 3; a wave parks the units it does not own ([source index among the three
+    // others][unit][lane]), the owner adds the four partial sums in WAVE order -- ((P0 + P1) + P2) + P3, the order of the one-wave
+    // combine this replaces: bit-identical -- and runs the unit's epilogue (activation in exact float32: ~40 instructions per value,
+    // which one wave of a one-wave-per-SIMD kernel used to do for the whole workgroup)
+#pragma unroll
+    for (int t = 0; t < MP; ++t)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const int own = (t * NT + ct) & 3;
+        if (own != wave) {
+          const int si = wave < own ? wave : wave - 1;
+          *(f32x4m*)(red + (((si * MP + t) * NT + ct) * 64 + lane) * 4) = acc[t][ct];
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MP; ++t)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        if (((t * NT + ct) & 3) != wave || !pv[t]) continue;
+        f32x4m tot;
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+          f32x4m part;
+          if (sw == wave) part = acc[t][ct];
+          else part = *(const f32x4m*)(red + ((((sw < wave ? sw : sw - 1) * MP + t) * NT + ct) * 64 + lane) * 4);
+          if (sw == 0) tot = part;
+          else { tot[0] += part[0]; tot[1] += part[1]; tot[2] += part[2]; tot[3] += part[3]; }
+        }
+        epilogue_unit(t, ct, tot);
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {
+      if (!pv[t]) continue;
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) epilogue_unit(t, ct, acc[t][ct]);
     }
   }
 }
