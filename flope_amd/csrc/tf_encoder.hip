@@ -699,15 +699,13 @@ extern "C" int flope_tf_create(int device_id, int input_dim, int model_dim, int 
     e->allocs.push_back(*bf.p);
     if (hipMemset(*bf.p, 0, bytes) != hipSuccess) return fin(tf_fail(nullptr, FLOPE_EHIP, "flope_tf_create: hipMemset failed"));
   }
-  static bool attr_done = false;
-  if (!attr_done) {
+  {                                                  // per create: the attribute is per device (a process-wide flag would leave a second GPU without it)
     hipFuncSetAttribute((const void*)tf_attn_mfma<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipFuncSetAttribute((const void*)tf_attn_mfma<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
 #define TF_ATTR(T_, A_, B_) hipFuncSetAttribute((const void*)tf_gemm_mfma<T_, A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)
     TF_ATTR(f16_t, false, false); TF_ATTR(f16_t, false, true); TF_ATTR(f16_t, true, false); TF_ATTR(f16_t, true, true);
     TF_ATTR(bf16_t, false, false); TF_ATTR(bf16_t, false, true); TF_ATTR(bf16_t, true, false); TF_ATTR(bf16_t, true, true);
 #undef TF_ATTR
-    attr_done = true;
   }
   *out = e;
   return FLOPE_OK;
