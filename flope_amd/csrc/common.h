@@ -12,6 +12,7 @@ typedef _Float16 f16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -21,11 +22,17 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x16 mfma32(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
 };
 template <> struct Elem<f16_t> {
   typedef f16x8 frag;
   static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
 

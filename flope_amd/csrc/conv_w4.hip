@@ -290,7 +290,37 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt) asm volatile("" ::"v"(osto[pt][0]), "v"(osto[pt][1]));
   __builtin_amdgcn_sched_barrier(0);
+#ifdef FLOPE_W4_MFMA32_TIMING
+  // TIMING-ONLY build (r05, results wrong by construction): every group of four v_mfma_f32_16x16x32 becomes two
+  // v_mfma_f32_32x32x16 on the same fragment registers and the same 16 accumulator registers -- the same FLOPs, LDS reads, DMA
+  // pieces, barriers and stores as a real 32x32 kernel would issue, so that the shape's effect on cycles AND on the clock the chip
+  // holds is measured on the real step before the kernel is rebuilt around it (profiles/r05_conv_w4_mfma32_timing.txt)
+  f32x16 acc32[MT];
+#define W4_ACCQ(pt_, ct_, q_) acc32[pt_][(ct_) * 4 + (q_)]
+#define W4_MFMA_GRP(C_, P_)                                                                                    \
+  do {                                                                                                         \
+    acc32[P_] = Elem<T>::mfma32(wf[C_][(2 * (P_)) & 3], xf[C_][P_], acc32[P_]);                                \
+    acc32[P_] = Elem<T>::mfma32(wf[C_][(2 * (P_) + 1) & 3], xf[C_][P_], acc32[P_]);                            \
+  } while (0)
+#define W4_MFMAS_PER_GRP 2
+#define W4_ACC_INIT()                                                                                          \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
+      _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) acc32[pt][ct * 4 + q] = b4[ct][q];                       \
+  } while (0)
+  W4_ACC_INIT();
+#pragma unroll
+  for (int pt = 0; pt < MT; ++pt) asm volatile("" : "+a"(acc32[pt]));
+#else
   f32x4 acc[MT][NT];
+#define W4_ACCQ(pt_, ct_, q_) acc[pt_][ct_][q_]
+#define W4_MFMA_GRP(C_, P_)                                                                                    \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
+      acc[P_][ct] = Elem<T>::mfma(wf[C_][ct], xf[C_][P_], acc[P_][ct]);                                        \
+  } while (0)
+#define W4_MFMAS_PER_GRP 4
 #define W4_ACC_INIT()                                                                                          \
   do {                                                                                                         \
     _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                          \
@@ -300,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #pragma unroll
   for (int pt = 0; pt < MT; ++pt)                          // ... and the accumulator init too (128 register moves)
     asm volatile("" : "+a"(acc[pt][0]), "+a"(acc[pt][1]), "+a"(acc[pt][2]), "+a"(acc[pt][3]));
+#endif
   frag wf[2][NT], xf[2][MT];                               // two fragment sets: sub-step u uses set u & 1
 
   W4_PSTAMP(2);
@@ -329,8 +360,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
         _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) xf[h][pt] = *(const frag*)(smem + xds[pt] + h * 16384); \
       }                                                                                                        \
       _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                            \
-        _Pragma("unroll") for (int pt = 0; pt < MT; ++pt)                                                      \
-          _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) acc[pt][ct] = Elem<T>::mfma(wf[h][ct], xf[h][pt], acc[pt][ct]); \
+        _Pragma("unroll") for (int pt = 0; pt < MT; ++pt) W4_MFMA_GRP(h, pt);                                  \
       W4_BARRIER();                                        /* buffer 1 / the shortcut's weight slot are free again */ \
     }                                                                                                          \
   } while (0)
@@ -365,8 +395,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #define W4_GRP(P_, C_, N_, wo_, nb_, nt_, NV_, KV_, DMA_, VG_)                                                 \
   do {                                                                                                         \
     if constexpr ((P_) < MT) {                             /* MT = 7: the eighth group does not exist */          \
-      _Pragma("unroll") for (int ct = 0; ct < NT; ++ct)                                                        \
-        acc[P_][ct] = Elem<T>::mfma(wf[C_][ct], xf[C_][P_], acc[P_][ct]);                                      \
+      W4_MFMA_GRP(C_, P_);                                                                                     \
       constexpr int X0_ = 2 * ((P_) - 2), X1_ = 2 * ((P_) - 2) + 1;   /* this group's two pixel fragments of the next set */ \
       if constexpr ((P_) < 2) {                                                                                \
         wf[N_][2 * (P_)] = *(const frag*)(smem + (wo_) + (2 * (P_)) * 1024);                                   \
@@ -378,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       if constexpr ((KV_) > 0 && (P_) * (KV_) + 0 < (NV_)) DMA_(((P_) * (KV_) + 0));                           \
       if constexpr ((KV_) > 1 && (P_) * (KV_) + 1 < (NV_)) DMA_(((P_) * (KV_) + 1));                           \
       if constexpr ((KV_) > 2 && (P_) * (KV_) + 2 < (NV_)) DMA_(((P_) * (KV_) + 2));                           \
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, W4_MFMAS_PER_GRP, 0);                                        \
       constexpr int NR_ = (P_) < 2 ? 2 : ((P_) < 6 ? (X0_ < MT ? 1 : 0) + (X1_ < MT ? 1 : 0) : 0);   /* reads of this group */ \
       if constexpr (NR_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, NR_, 0);                              \
       if constexpr (VG_) W4_VMEM_GROUP(P_, NV_, KV_);                                                          \
@@ -509,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[ct * 4 + q] = acc[pt][ct][q];
+      for (int q = 0; q < 4; ++q) v[ct * 4 + q] = W4_ACCQ(pt, ct, q);
     if constexpr (RES) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -606,6 +635,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
 #undef W4_DSTAMP
 #undef W4_GSTAMP
 #undef W4_ACC_INIT
+#undef W4_ACCQ
+#undef W4_MFMA_GRP
+#undef W4_MFMAS_PER_GRP
 #undef W4_DS_CHAIN
 #undef W4_DSTEP
 #undef W4_ISSUE_DS

@@ -30,11 +30,11 @@ for spec in specs:
     for k, v in opts.items():
         e.set_option(k, v)
     e.load_state_dict(sd)
-    for _ in range(5):
+    for _ in range(int(os.environ.get("WARM", 5))):      # WARM=100: past the ~30 ms the device needs to reach its sustained clock
         e.forward_into(x, 2, None, R)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 40
+    n = int(os.environ.get("N", 40))
     for _ in range(n):
         e.forward_into(x, 2, None, R)
     torch.cuda.synchronize()
