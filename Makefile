@@ -25,11 +25,14 @@ $(HARNESS): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack
 	g++ -O2 -fPIC -shared -std=c++17 -I$(CSRC) -o $@ $<
 
 # the same host code under AddressSanitizer + UBSan (sanitizers run on the CPU build only):
-#   make asan && LD_PRELOAD=$$(gcc -print-file-name=libasan.so) FLOPE_HOST_HARNESS=tests/host_harness/libflope_host_harness_asan.so python -m pytest tests/test_host.py -q -k harness
+#   make asan-test      (builds the sanitized harness and runs tests/test_host.py against it; leak detection is off because the
+#                        interpreter's own libcrypto allocations are reported as leaks at exit)
 HARNESS_ASAN := tests/host_harness/libflope_host_harness_asan.so
 $(HARNESS_ASAN): tests/host_harness/harness.cpp $(CSRC)/pose_math.h $(CSRC)/host_pack.h $(CSRC)/w4_sched.h
 	g++ -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -fPIC -shared -std=c++17 -I$(CSRC) -o $@ $<
 asan: $(HARNESS_ASAN)
+asan-test: $(HARNESS_ASAN)
+	ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$$(gcc -print-file-name=libasan.so) FLOPE_HOST_HARNESS=$(HARNESS_ASAN) python -m pytest tests/test_host.py -q
 
 # diagnostic build (ablation bits + in-kernel clock stamps of conv_stag; results of dbg options are wrong by construction):
 #   make dbg && FLOPE_AMD_LIB=build/dbg/libflope_amd_dbg.so python tools/clock_probe.py
@@ -45,7 +48,7 @@ clean:
 	rm -rf build $(LIB) $(HARNESS)
 
 # stand-alone measurement programs used by tools/collect_profiles.sh and DESIGN.md section 9 (not part of the library)
-TOOLBINS := build/fetch_calib build/launch_floor build/loop_probe build/dma_issue_probe
+TOOLBINS := build/fetch_calib build/launch_floor build/loop_probe build/loop_probe32 build/dma_issue_probe
 build/fetch_calib: tools/calib/fetch_calib.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
@@ -55,9 +58,12 @@ build/launch_floor: tools/calib/launch_floor.hip
 build/loop_probe: tools/probes/loop_probe.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+build/loop_probe32: tools/probes/loop_probe32.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 build/dma_issue_probe: tools/probes/dma_issue_probe.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 tools: $(TOOLBINS)
 
-.PHONY: all clean dbg tools asan
+.PHONY: all clean dbg tools asan asan-test

@@ -80,6 +80,51 @@ def cpu_baseline(crop: int, batch: int = 16, budget_s: float = 12.0):
             "sample": f"{len(times)} x ({batch} crops {crop}x{crop} fp32, torch CPU eval-mode oracle + SVD Procrustes), median"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without an outer launcher: start `python -m torch.distributed.run` (one rank per GPU) as a CHILD
+    process -- before this process has touched the GPU, and never by exec -- relay rank 0's JSON line and return the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the launched ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def no_autotune_child(args) -> dict | None:
+    """The same run in a fresh process with the engine's default schedule and no set-up measurement (the tuned number
+    next to the untuned one -- most of r04's gain was the device reaching its sustained clock during autotune, not the schedule)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--dtype", args.dtype, "--crop", str(args.crop), "--batch", str(args.batch), "--no-autotune", "--no-alt", "--no-cpu-baseline"]
+    try:
+        proc = subprocess.run(cmd, env=dict(os.environ, FLOPE_BENCH_CHILD="1"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True, timeout=300)
+        for ln in proc.stdout.splitlines():
+            if ln.startswith('{"metric"'):
+                j = json.loads(ln)
+                return {"value": j["value"], "ms_per_step": j["ms_per_step"], "ms_per_step_median": j.get("ms_per_step_median"),
+                        "note": "fresh process, default schedule, no autotune; same steps / warm-up"}
+    except (subprocess.SubprocessError, ValueError, KeyError, OSError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +141,8 @@ def main():
     args = ap.parse_args()
     if args.cfg4:
         args.steps, args.batch, args.crop = 32, 256, 224
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no outer launcher: become one (nothing has touched the GPU yet)
+        raise SystemExit(self_launch(args.gpus))
 
     from flope_amd import distributed as D
     from flope_amd import engine as E
@@ -278,6 +325,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(S, 16)
         big = cpu_baseline(S, 256, budget_s=8.0)
         out["cpu_baseline"]["batch_256"] = {"value": big["value"], "sample": big["sample"]}
+
+    if rank == 0 and world == 1 and not args.no_autotune and os.environ.get("FLOPE_BENCH_CHILD") != "1":
+        out["no_autotune"] = no_autotune_child(args)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -33,7 +33,7 @@
 //     pixels x 64 bytes; the store path takes ~66 cycles per such instruction (64 per workgroup tile = 4.2 k cycles, measured:
 //     tools/probes/store_probe.hip, profiles/r04_store_probe.txt).  The packed outputs now pass through a wave-private 2 KB LDS
 //     image (XOR-swizzled, conflict-free both ways) and leave as 8 whole 128-byte lines per instruction: 2.9 k cycles.  Only the
-//     order of the stores changes -- same bytes, same addresses.  (-DFLOPE_W4_MFMA_STORES builds the r03 order for A/B runs.)
+//     order of the stores changes -- same bytes, same addresses.
 #include "common.h"
 #include "w4_sched.h"
 #ifndef FLOPE_W4_SPREAD
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
   // maps of a 224 x 224 crop batch -- no ragged last tile -- and 224-pixel tiles land closer under a whole number of rounds);
   // 6, 5, 4 -> 192, 160, 128: launches of fewer than ~200 tiles (layer 4, batch slices) fill more of the chip with smaller ones
   constexpr int BM = 2 * MT * 16, WPXB = MT * 16, TILE_B = 128 * 64, DT_B = 2 * TILE_B, NT = 4;
-  static_assert(MT >= 4 && MT <= 8, "conv_w4: 4..8 pixel tiles per wave");
+  static_assert(MT >= 5 && MT <= 8, "conv_w4: 5..8 pixel tiles per wave");
   constexpr int NBD = w4_ring(PT, DSF && PERS);
   static_assert(NBD >= 3, "conv_w4: this variant does not fit the CU's LDS");
   constexpr int PATCH_B = PT * 8192;
@@ -268,15 +268,10 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       // whose table entry sits at (wpx, pp)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-#ifdef FLOPE_W4_MFMA_STORES
-        osto[pt][c] = a2[1] + (unsigned)(cb * 2 + c * 64);
-        okl[pt][c] = PERS || (m0 + wpx * WPXB + pt * 16 + pcol < mend);
-#else
         const int pp = c * 8 + (lane >> 3);
         osto[pt][c] = *(const unsigned*)(smem + SCR_B + (wpx * 16 + pp) * 400 + pt * 48 + 36) +
                       (unsigned)((ntile * 128 + wch * 64) * 2 + (lane & 7) * 16);
         okl[pt][c] = PERS || (m0 + wpx * WPXB + pt * 16 + tile_px_w4(pp) < mend);
-#endif
       }
     }
   }
@@ -561,7 +556,6 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[c][q] = pk_out16<T>(pack2<T>(v[c * 8 + q * 2], v[c * 8 + q * 2 + 1]), p.relu);
-#ifndef FLOPE_W4_MFMA_STORES
 #pragma unroll
     for (int c = 0; c < 2; ++c) *(u32x4*)(lscr + r16 * 128 + (((c * 4 + g) ^ (r16 & 7)) << 4)) = o[c];
 #pragma unroll
@@ -569,7 +563,6 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(const ConvP p) {
       const int pp = c * 8 + (lane >> 3);
       o[c] = *(const u32x4*)(lscr + pp * 128 + (((lane & 7) ^ (pp & 7)) << 4));
     }
-#endif
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       if (okl[pt][c]) *(u32x4*)((char*)p.out + osto[pt][c]) = o[c];
@@ -659,7 +652,7 @@ static constexpr size_t w4_lds_bytes(int pt, bool own_ds_slot) {
   return (size_t)2 * pt * 8192 + (size_t)(w4_ring(pt, own_ds_slot) + (own_ds_slot ? 1 : 0)) * 16384 + 12800;
 }
 
-// instantiated variants: one tile per workgroup at MT = 8, 7 (PT = 4, 5, 6) and MT = 6, 5, 4 (PT = 4); the class walk at MT = 7
+// instantiated variants: one tile per workgroup at MT = 8, 7 (PT = 4, 5, 6) and MT = 6, 5 (PT = 4; r05: 4 dropped, the planner's floor is 5); the class walk at MT = 7
 // (PT = 4, 5; with a folded shortcut the 6-round patch leaves no room for the shortcut's own weight slot)
 #define W4_FOR_VARIANTS(X, T)                                                                                  \
   X(T, 4, false, false, false, 8) X(T, 4, true, false, false, 8) X(T, 4, false, true, false, 8)                \
@@ -670,7 +663,6 @@ static constexpr size_t w4_lds_bytes(int pt, bool own_ds_slot) {
   X(T, 6, false, false, false, 7) X(T, 6, true, false, false, 7) X(T, 6, false, true, false, 7)                \
   X(T, 4, false, false, false, 6) X(T, 4, true, false, false, 6) X(T, 4, false, true, false, 6)                \
   X(T, 4, false, false, false, 5) X(T, 4, true, false, false, 5) X(T, 4, false, true, false, 5)                \
-  X(T, 4, false, false, false, 4) X(T, 4, true, false, false, 4) X(T, 4, false, true, false, 4)                \
   X(T, 4, false, false, true, 7) X(T, 4, true, false, true, 7) X(T, 4, false, true, true, 7)                   \
   X(T, 5, false, false, true, 7) X(T, 5, true, false, true, 7) X(T, 5, false, true, true, 7)
 
@@ -687,7 +679,7 @@ extern "C" int flope_conv_w4_init() {
 // lds bytes of a variant: 2 patch buffers, the weight ring (+ 1 double tile for a persistent workgroup's folded shortcut), 12.5 KB in
 // which the lanes trade their shares of the address table and the epilogue builds its line image; 0 = not instantiated
 extern "C" size_t flope_conv_w4_lds(int pt, int mt, int dsf, int pers) {
-  if (pt < 4 || pt > 6 || mt < 4 || mt > 8 || (mt < 7 && pt != 4) || (pers && (mt != 7 || pt > 5))) return 0;
+  if (pt < 4 || pt > 6 || mt < 5 || mt > 8 || (mt < 7 && pt != 4) || (pers && (mt != 7 || pt > 5))) return 0;
   return w4_lds_bytes(pt, dsf && pers);
 }
 
@@ -699,7 +691,7 @@ extern "C" size_t flope_conv_w4_lds(int pt, int mt, int dsf, int pers) {
 extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int grid_blocks, int mt, void* stream) {
   const int pt = p->patch_rows_max;
   const bool pers = grid_blocks < p->total_tiles;
-  if (mt < 4 || mt > 8 || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 ||
+  if (mt < 5 || mt > 8 || p->mtiles != (p->M + 32 * mt - 1) / (32 * mt) || p->stride != 1 || p->ntaps != 9 || p->Cin % 64 || p->Cout % 128 ||
       !p->skew || !p->mg_pitch || p->ksplit > 1 || (p->res && p->ds_in) || (p->ds_in && (p->ds_Cin % 64 || !p->ds_w)) ||
       grid_blocks < p->ntiles || grid_blocks > p->total_tiles || grid_blocks % p->ntiles || p->total_tiles != p->mtiles * p->ntiles)
     return (int)hipErrorInvalidValue;

@@ -38,9 +38,6 @@ extern "C" int flope_conv_r4_ok(const ConvP* p);
 extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream);
 extern "C" int flope_conv_w4_launch(const ConvP* p, int dtype, int grid_blocks, int mt, void* stream);
 extern "C" size_t flope_conv_w4_lds(int pt, int mt, int dsf, int pers);
-extern "C" int flope_conv_w8_init();
-extern "C" int flope_conv_w8_launch(const ConvP* p, int dtype, void* stream);
-extern "C" size_t flope_conv_w8_lds(int pt);
 extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
@@ -107,7 +104,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_w8 = 0;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -240,8 +237,8 @@ void plan_conv(flope_engine* e, Conv& c) {
     if (P == 7) P = 8;                                 // (every round is 8 KB of L2 -> LDS traffic per half-chunk and tile)
     const size_t lds = (size_t)6 * sbn * 64 + (size_t)2 * P * 8192;   // 3 double tiles + 2 patch buffers
     if (P <= 8 && lds <= kLdsMax) { c.stag = 1; c.stag_patch_bytes = P; c.stag_lds = lds; }
-    if (c.cout >= 128)                                  // the 4-wave kernel's smaller tiles (conv_w4.hip, MT = 4..7)
-      for (int mt = 4; mt <= 7; ++mt) {
+    if (c.cout >= 128)                                  // the 4-wave kernel's smaller tiles (conv_w4.hip, MT = 5..7)
+      for (int mt = 5; mt <= 7; ++mt) {
         const long pcs = (long)patch_rows(c, B, 32 * mt, false) * (Wip + 2) * 4;
         const int Pm = std::max(4, (int)((pcs + 511) / 512));
         c.w4_patch[mt] = (mt == 7 ? Pm <= 6 : Pm == 4) ? Pm : 0;      // below 7: the 4-round instantiations only
@@ -418,7 +415,6 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     if (s == 0) s = flope_conv_stag_init();
     if (s == 0) s = flope_conv_gstag_init();
     if (s == 0) s = flope_conv_w4_init();
-    if (s == 0) s = flope_conv_w8_init();
     if (s == 0) s = flope_conv_r4_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
@@ -541,9 +537,9 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { prev = e->opt_rows_grid; e->opt_rows_grid = value < 0 ? -1 : value; return prev; }   // layer-1 persistent grid: 0 = one workgroup per CU, -1 = the slice's share of the CUs, > 0 = that many
   else if (!strcmp(name, "split")) { prev = e->opt_split; e->opt_split = value < 0 ? 0 : value; return prev; }   // 0: default 3/8 : 5/8; 1..100: percent of the batch in slice 0; > 100: (value - 100) images
   else if (!strcmp(name, "fc1_packed")) { prev = e->opt_fc1_packed; e->opt_fc1_packed = value != 0; return prev; }
-  else if (!strcmp(name, "w4mtlo")) { prev = e->opt_w4mtlo; e->opt_w4mtlo = value <= 0 ? 0 : (value < 4 ? 4 : (value > 8 ? 8 : value)); return prev; }   // smallest tile height the per-launch choice may take (0: 7 with two slices in flight, 5 alone)
+  else if (!strcmp(name, "w4mtlo")) { prev = e->opt_w4mtlo; e->opt_w4mtlo = value <= 0 ? 0 : (value < 5 ? 5 : (value > 8 ? 8 : value)); return prev; }   // smallest tile height the per-launch choice may take (0: 7 with two slices in flight, 5 alone)
   else if (!strcmp(name, "lag")) { prev = e->opt_lag; e->opt_lag = value < 0 ? 0 : (value > 500 ? 500 : value); return prev; }   // microseconds by which the last batch slice starts late (default 20; 0 = off)
-  else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value >= 4 && value <= 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 4..8 = 128..256 pixels (where the shape has that instantiation)
+  else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value >= 5 && value <= 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 5..8 = 160..256 pixels (where the shape has that instantiation)
   else if (!strcmp(name, "fc2_k4")) { prev = e->opt_fc2_k4; e->opt_fc2_k4 = value != 0; return prev; }            // fc_rot: K split over the four waves of a workgroup per image
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
@@ -551,7 +547,6 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
   else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = value != 0; return prev; }
-  else if (!strcmp(name, "w8")) { prev = e->opt_w8; e->opt_w8 = value != 0; return prev; }   // conv_w8 (8 waves, two per SIMD, 256-pixel tiles) in place of conv_w4
   else if (!strcmp(name, "w4cw")) { prev = e->opt_w4cw; e->opt_w4cw = value < 0 ? 0 : (value > 64 ? 64 : value); return prev; }   // conv_w4 class walk: tiles per persistent workgroup aimed at (0 / 1 = one tile per workgroup)
   else if (!strcmp(name, "w4cwf")) { prev = e->opt_w4cwf; e->opt_w4cwf = value & 3; return prev; }   // ... bit 0: also with several batch slices in flight, bit 1: also where the walk fills < 85 % of the slice's CUs
   else if (!strcmp(name, "prio")) { prev = e->opt_prio; e->opt_prio = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
@@ -749,7 +744,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       // cost model fitted to B = 16 / 31 @ 512^2 (layer 3, 128 tiles, x2: 40 vs 37 us -- a loss; layer 4, 124 tiles, x2: a win;
       // layer 4, 64 tiles, x4: 37 vs 55 us): gain = T (1 - 1/s) - (5 us + 0.066 us * tiles * s), T = 0.75 us per double step.
       int ksp = 1;
-      if (e->opt_ksplit && c.stag == 1 && e->cur_slices == 1 && !e->opt_persist && p.total_tiles * 2 <= e->num_cus) {
+      if (e->opt_ksplit && c.stag == 1 && e->plan_slices == 1 && !e->opt_persist && p.total_tiles * 2 <= e->num_cus) {   // plan_slices: the profile pass (one stream) times the kernels the production schedule of this batch runs
         const int bodies = c.cin / 64;
         const double T = 0.75 * 9.0 * bodies;
         double best = 0.0;
@@ -774,13 +769,6 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         // of the chip x the time of a tile -- ~15 k cycles of prologue + epilogue, and per double step 128 cycles of MFMAs per
         // pixel tile + ~500 of everything else (r03 stamps: 1.52 k at 8, 1.4 k at 7); ties go to the larger tile
         int mt = 8, ptr = c.stag_patch_bytes;
-        if (e->opt_w8 && flope_conv_w8_lds(ptr) != 0) {
-          fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
-          SMARK();
-          c.last_kernel = "conv_w8_kernel<256x128>"; c.last_detail = "[256 px tiles, 8 waves]";
-          K_TRY(e, c.name.c_str(), flope_conv_w8_launch(&p, dt, stream));
-          continue;
-        }
         if (e->opt_w4mt != 8) {
           const double dsteps = 9.0 * (c.cin / 64 + (p.ds_in ? 1 : 0));
           // Measured (profiles/r03_conv_w4_tile_height_ab.txt): with two batch slices in flight only 224 against 256 pays (+1.8 % on

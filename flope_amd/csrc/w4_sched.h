@@ -28,7 +28,7 @@
 #pragma once
 
 #ifndef W4_HD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define W4_HD __host__ __device__
 #else
 #define W4_HD
@@ -77,7 +77,7 @@ W4_HD constexpr int w4_res_first(int MT) { return 8; }            // index of th
 //   double tiles were read there, its buffer-1 burst was due at its barrier 3, its buffer-0 burst at its barrier 8), this body's
 //   buffer-1 burst from D = 3 on, this body's buffer-0 pieces at D = 8.  Double tile k of the current body is issued at double step
 //   k - PD of the current body, or (k < PD) at double step 9 + k - PD of the body before.
-// (tgw: pieces of a double tile per wave -- 4 on the 4-wave kernel, 2 on the 8-wave one, conv_w8.hip)
+// (tgw: pieces of a double tile per wave -- 4 on the 4-wave kernel; r04's 8-wave experiment used 2)
 W4_HD constexpr int w4_wait_n(int D, int PD, int PW, int spread, int boundary_ops, int res_mt, int tgw = W4_TGW) {
   int issued = 0, last_needed = 0;                       // running count of issued operations; 1-based index of the youngest needed one
   // body -1 (everything needed; its double tiles 9 .. belong to the current body: index k = d + PD - 9)

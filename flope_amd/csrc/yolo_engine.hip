@@ -48,6 +48,7 @@ extern "C" int flope_yread_launch(const void* src, int is_f32, int H, int W, int
 // strict float32 mode (yolo_f32.hip): the same graph on float32 maps, plain fused-multiply-add convolutions
 extern "C" int flope_y32_conv_launch(const YConvP* p, void* stream);
 extern "C" int flope_y32m_conv_launch(const YConvP* p, void* stream);
+extern "C" int flope_y32m_conv_ok(const YConvP* p);
 extern "C" int flope_y32m_multi_add_conv(YMultiP* m, const YConvP* p);
 extern "C" int flope_y32m_multi_add_dw(YMultiP* m, const YDwP* p);
 extern "C" int flope_y32m_multi_launch(const YMultiP* m, const YMultiP* m_dev, void* stream);
@@ -464,7 +465,7 @@ struct Builder {
 int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
   if (e->dtype == FLOPE_DT_F32) {
     switch (op.kind) {
-      case Op::CONV: return e->opt_f32mfma ? flope_y32m_conv_launch(&op.conv, st) : flope_y32_conv_launch(&op.conv, st);
+      case Op::CONV: return (e->opt_f32mfma && flope_y32m_conv_ok(&op.conv)) ? flope_y32m_conv_launch(&op.conv, st) : flope_y32_conv_launch(&op.conv, st);   // (a shape the MFMA kernel does not take: the plain kernel)
       case Op::DW: return flope_y32_dw_launch(&op.dw, st);
       case Op::POOL: return flope_y32_pool_launch(&op.pool, st);
       case Op::UP: return flope_y32_up_launch(&op.up, st);
@@ -543,7 +544,8 @@ int build_schedules(flope_yolo* e) {
     for (int i = 0; i < n; ++i)
       if (e->ops[i].level == lv) {
         const Op& op = e->ops[i];
-        if (op.kind == Op::CONV || op.kind == Op::DW) classes[0].push_back(i);
+        if (f32 && op.kind == Op::CONV && !flope_y32m_conv_ok(&op.conv)) single.push_back(i);   // launch_op falls back to the plain kernel
+        else if (op.kind == Op::CONV || op.kind == Op::DW) classes[0].push_back(i);
         else if (op.kind == Op::BNECK && e->opt_bneck) classes[e->opt_bneck == 2 ? 1 : 0].push_back(i);
         else single.push_back(i);
       }

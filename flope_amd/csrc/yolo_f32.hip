@@ -303,7 +303,7 @@ extern "C" int flope_y32_pool_launch(const YPoolP* p, void* stream) {
   if (p->n < 1 || p->n > 3) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)4 * p->H * p->W * 4 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (lds <= 160 * 1024 && p->C % 4 == 0 && p->ldi % 4 == 0) {
+  if (lds <= 160 * 1024 && p->C % 4 == 0 && p->ldi % 4 == 0 && !((uintptr_t)p->in & 15)) {   // (the LDS form reads float32x4 pixels)
     if (p->n == 1) hipLaunchKernelGGL(y32_pool_lds_kernel<1>, dim3(p->C / 4), dim3(1024), lds, st, *p);
     else if (p->n == 2) hipLaunchKernelGGL(y32_pool_lds_kernel<2>, dim3(p->C / 4), dim3(1024), lds, st, *p);
     else hipLaunchKernelGGL(y32_pool_lds_kernel<3>, dim3(p->C / 4), dim3(1024), lds, st, *p);
@@ -618,6 +618,10 @@ __global__ __launch_bounds__(256) void y32m_conv_kernel(const YConvP p) {
 // where that still leaves two workgroups per CU.  -> grid (nbx, nby)
 static bool y32m_geometry(const YConvP* p, bool* splitk, int* mp, int* nbx, int* nby, int mp2_from = 32768) {
   if ((p->k != 1 && p->k != 3) || p->Cin % 8 || p->M < 1 || !p->w32m || !p->bias32m || (p->nt32m != 1 && p->nt32m != 2 && p->nt32m != 4)) return false;
+  // what the epilogue assumes: float32x4 stores -- 16-byte aligned rows -- and, for the transposed-conv scatter, whole
+  // units of 4 NT channels per (dy, dx) block
+  // (prediction rows, out_mode 1, have an odd pitch and are stored element by element)
+  if ((p->out_mode != 1 && (((uintptr_t)p->out & 15) || (p->ldo & 3))) || (p->out_mode == 2 && p->dc % (4 * p->nt32m))) return false;
   const int rows = p->out_mode == 2 ? 4 * p->dc : p->Cout;
   *splitk = p->M <= 4096 && p->k16steps >= 8;
   *mp = (!*splitk && p->M >= mp2_from) ? 2 : 1;          // (two pixel tiles per wave halve the weight loads per MFMA; inside a shared grid the other ops keep the CUs filled)
@@ -625,6 +629,13 @@ static bool y32m_geometry(const YConvP* p, bool* splitk, int* mp, int* nbx, int*
   *nbx = *splitk ? tiles : (tiles + 3) / 4;
   *nby = (rows + 16 * p->nt32m - 1) / (16 * p->nt32m);
   return true;
+}
+
+// does the MFMA kernel take this op?  (no: the engine launches the plain fused-multiply-add kernel instead, and keeps the op out of
+// the shared grids -- yolo_engine.hip launch_op / build_schedules)
+extern "C" int flope_y32m_conv_ok(const YConvP* p) {
+  bool splitk; int mp, nbx, nby;
+  return y32m_geometry(p, &splitk, &mp, &nbx, &nby) ? 1 : 0;
 }
 
 // float32 detector convolution on the matrix cores; p->w32m / bias32m / k16steps / nt32m from the builder (yolo_engine.hip pack)

@@ -180,15 +180,35 @@ class PoseEngine:
     # schedule candidates of autotune(): engine options whose best value differs from box to box and from batch to batch
     # (same-run pairs move by up to +-2 %, and boxes of one pool differ by up to 12 % in clock)
     # (one slice instead of two is not a candidate: below ~130 crops it would switch split-K on, which sums in another order)
-    TUNE_CANDIDATES = ({}, {"w4cw": 4, "w4cwf": 1}, {"lag": 0}, {"split": 38}, {"split": 44})
+    # "split38" / "split716": slice 0 = 3/8 or 7/16 of the batch as an ABSOLUTE image count on a multiple of 8 (engine option
+    # split = 100 + images), so that every layer's tiles stay whole in both slices -- a percentage would give 97 / 159 at B = 256
+    # (ADVICE r4): resolved per batch by tune_candidates()
+    TUNE_CANDIDATES = ({}, {"w4cw": 4, "w4cwf": 1}, {"lag": 0}, {"split": "3/8"}, {"split": "7/16"})
+
+    @classmethod
+    def tune_candidates(cls, batch: int):
+        """TUNE_CANDIDATES with the slice fractions resolved for `batch` (candidates that coincide with the default are dropped)."""
+        out = []
+        for c in cls.TUNE_CANDIDATES:
+            c = dict(c)
+            if isinstance(c.get("split"), str):
+                num, den = (int(v) for v in c["split"].split("/"))
+                first = (batch * num // den) & ~7
+                if first < 8 or first >= batch or first == ((batch // 2) & ~7):
+                    continue
+                c["split"] = 100 + first
+            if c not in out:
+                out.append(c)
+        return out
 
     def autotune(self, x: torch.Tensor, fmt: int, rounds: int = 5, per_round: int = 5, candidates=None) -> dict:
         """Pick the launch schedule for THIS device and THIS batch by measurement: every candidate option set runs `per_round`
         forwards per round, candidates interleaved over `rounds` rounds (so that none of them owns the slow steps of a GPU that
         is still ramping its clock up), timed with events on the caller's stream; the set with the smallest median step is left
         in force.  ~rounds x per_round x len(candidates) forwards (a hundred milliseconds at B = 256).  Results do not depend on
-        the choice: every candidate is bit-identical (tests/test_gpu_parity.py)."""
-        cands = [dict(c) for c in (candidates if candidates is not None else self.TUNE_CANDIDATES)]
+        the choice: every candidate is bit-identical (tests/test_gpu_parity.py).  If a forward fails the options the engine had
+        on entry are restored before the exception propagates."""
+        cands = [dict(c) for c in (candidates if candidates is not None else self.tune_candidates(x.shape[0]))]
         R = torch.empty((x.shape[0], 9), dtype=torch.float32, device=self.device)
         self._check_into(x, fmt, R=(R, 9))
         names = sorted({k for c in cands for k in c})
@@ -196,24 +216,27 @@ class PoseEngine:
         for k, v in base.items():
             self.set_option(k, v)
         times = [[] for _ in cands]
-        with torch.cuda.device(self.device):
-            for _ in range(rounds):
-                for ci, c in enumerate(cands):
-                    for k in names:
-                        self.set_option(k, c.get(k, base[k]))
-                    self.forward_into(x, fmt, None, R)                          # (first forward of a new option set: not timed)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(per_round):
-                        self.forward_into(x, fmt, None, R)
-                    e1.record()
-                    e1.synchronize()
-                    times[ci].append(e0.elapsed_time(e1) / per_round)
-        med = [sorted(t)[len(t) // 2] for t in times]
-        best = min(range(len(cands)), key=lambda i: med[i])
-        for k in names:
-            self.set_option(k, cands[best].get(k, base[k]))
-        return {"chosen": cands[best], "median_ms": {str(c): round(m, 4) for c, m in zip(cands, med)}}
+        chosen = None
+        try:
+            with torch.cuda.device(self.device):
+                for _ in range(rounds):
+                    for ci, c in enumerate(cands):
+                        for k in names:
+                            self.set_option(k, c.get(k, base[k]))
+                        self.forward_into(x, fmt, None, R)                      # (first forward of a new option set: not timed)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(per_round):
+                            self.forward_into(x, fmt, None, R)
+                        e1.record()
+                        e1.synchronize()
+                        times[ci].append(e0.elapsed_time(e1) / per_round)
+            med = [sorted(t)[len(t) // 2] for t in times]
+            chosen = cands[min(range(len(cands)), key=lambda i: med[i])]
+        finally:
+            for k in names:
+                self.set_option(k, (chosen if chosen is not None else base).get(k, base[k]))
+        return {"chosen": chosen, "median_ms": {str(c): round(m, 4) for c, m in zip(cands, med)}}
 
     def flops(self, batch: int) -> float:
         return float(self.lib.flope_forward_flops(self.handle, batch))

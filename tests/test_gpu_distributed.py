@@ -24,11 +24,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench_two_ranks(extra_env):
+def _bench_two_ranks(extra_env, outer_launcher=True):
+    """outer_launcher: the driver's documented form (`python -m torch.distributed.run ... bench.py --gpus 2`); without it bench.py
+    is started bare (`python bench.py --gpus 2`, no WORLD_SIZE) and must start its own ranks as a child process."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-alt"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] if outer_launcher else []
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                                         "--no-cpu-baseline", "--no-alt"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -48,7 +53,8 @@ def test_bench_two_ranks_over_rccl():
     _check(_bench_two_ranks({}))
 
 
-def test_bench_two_ranks_rehearsed_on_one_gpu():
-    out = _bench_two_ranks({"FLOPE_BENCH_REHEARSE": "1"})
+@pytest.mark.parametrize("outer_launcher", [True, False])
+def test_bench_two_ranks_rehearsed_on_one_gpu(outer_launcher):
+    out = _bench_two_ranks({"FLOPE_BENCH_REHEARSE": "1"}, outer_launcher)
     _check(out)
     assert "REHEARSAL" in out["data"]

@@ -32,12 +32,13 @@ def _engine(ysd, H, W, imgsz, dtype="f16"):
 
 
 @pytest.mark.parametrize("H,W,imgsz,dtype,tol,tol_emu", [(1080, 1920, 1280, "f16", 5e-3, None), (360, 640, 640, "f16", 5e-3, 3e-3), (300, 500, 320, "f16", 5e-3, None),
-                                                         (250, 333, 640, "bf16", None, 1.5e-2)])     # measured (r04): 2.2e-3 / 2.0e-3, 1.4e-3 / 1.6e-3 / 1.2e-2
+                                                         (250, 333, 640, "bf16", 8e-2, 1.5e-2)])     # measured (r04): 2.2e-3 / 2.0e-3, 1.4e-3 / 1.6e-3 / 1.2e-2; bf16 vs float32 4.3e-2
 def test_every_graph_output_vs_oracle(ysd, H, W, imgsz, dtype, tol, tol_emu):
     """Every graph output and head row block against the float32 oracle (tol), and -- r04 -- against the oracle run WITH the device
     path's rounding points (Y.forward_layers(..., emulate=dtype): folded weights and stored maps in the 16-bit type, float32
-    accumulation; tol_emu).  bf16 is held to the emulating oracle only: its 8 mantissa bits over 23 layers put the float32 forward
-    4e-2 away from ANY bf16 evaluation of this graph (the emulation itself sits there), which is what r02's 8e-2 band had measured."""
+    accumulation; tol_emu).  bf16 keeps BOTH bounds: the tight one against its emulation, and the loose float32 band as the
+    independent check -- its 8 mantissa bits over 23 layers put the float32 forward 4e-2 away from ANY bf16 evaluation of this graph (the
+    emulation itself sits there), so 8e-2 catches a shared design error (a wrong fold, a dropped rounding point) and nothing finer."""
     from flope_amd.yolo_weights import synthetic_frame
     img = synthetic_frame(3, H, W)
     y = _engine(ysd, H, W, imgsz, dtype)
@@ -260,9 +261,14 @@ def test_detector_end_to_end_vs_fp32_oracle(ysd):
     y.close()
 
 
-def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path):
+@pytest.mark.parametrize("yolo_dtype", [None, "f16"])
+def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path, yolo_dtype):
     """BASELINE configs[2] end to end: FastPosePredictor(device, yolo_path=<state_dict file>, posenet_path, intrin_path)
-    on a 1080p frame -- detector, crops, PoseResNet, Procrustes, depth lift, all on the device."""
+    on a 1080p frame -- detector, crops, PoseResNet, Procrustes, depth lift, all on the device.
+    Default detector (r05): the exact-float32 one -- the `int16` boxes and the `uint8` mask that
+    fast_pose_predictor.py:49-56 hands to the pose path EQUAL the float32 oracle's.  `yolo_dtype="f16"` is the opt-in fast detector:
+    the same number of boxes except for candidates within 0.01 of the confidence threshold (listed in the failure message), every
+    other box within 2 px of its partner, mask XOR < 2 % -- the count is asserted, the comparison can no longer be skipped."""
     import yaml
     from flope_amd.yolo_weights import synthetic_frame
     from sunflower.predictor.fast_pose_predictor import FastPosePredictor
@@ -275,7 +281,8 @@ def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path
     torch.save(state_dict, ckpt)
     intr.write_text(yaml.safe_dump(dict(fx=1400.0, fy=1400.0, cx=W / 2, cy=H / 2, h=H, w=W)))
     from oracle import posenet_ref as O
-    pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr))
+    pred = FastPosePredictor("cuda", str(yolo_f), str(ckpt), str(intr), **({} if yolo_dtype is None else {"yolo_dtype": yolo_dtype}))
+    assert pred.yolo.dtype == (yolo_dtype or "f32")
     bb, mask = pred.get_bbox_mask(img)
     assert bb.dtype == np.int16 and bb.shape[0] >= 5 and mask.shape == (H, W)
     Rt = pred.get_flower_poses(img, depth)
@@ -284,11 +291,24 @@ def test_fast_pose_predictor_with_the_builtin_detector(ysd, state_dict, tmp_path
     assert Rt is not None and Rt.shape == ref.shape and Rt.shape[0] >= 3
     assert np.abs(Rt[:, :3, :3] - ref[:, :3, :3]).max() <= 1e-3
     assert np.linalg.norm(Rt[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-5
-    # and the detector half against the fp32 oracle: same number of boxes within a pixel, or a marginal candidate differs
+    # the detector half against the float32 oracle
     rb, rmask = Y.get_bbox_mask(ysd, img, 1280)
-    if rb.shape == bb.shape:                         # near-equal confidences may swap two rows: compare as sets
-        for r in rb.astype(int):
-            assert np.abs(bb.astype(int) - r).max(axis=1).min() <= 2, r
+    if yolo_dtype is None:
+        assert np.array_equal(bb, rb) and np.array_equal(mask, rmask)
+        return
+    _, rconf, _ = Y.detect(ysd, img, 1280)
+    _, conf, _, _, _ = pred.yolo.detect(img)
+    thr = 0.25
+    marg_r = [i for i, c in enumerate(rconf) if c < thr + 0.01]          # kept candidates that a 16-bit evaluation may drop ...
+    marg_d = [i for i, c in enumerate(conf) if c < thr + 0.01]           # ... or that only the 16-bit evaluation keeps
+    assert len(rconf) == rb.shape[0] and len(conf) == bb.shape[0]
+    assert abs(bb.shape[0] - rb.shape[0]) <= len(marg_r) + len(marg_d), (bb.shape, rb.shape, [float(rconf[i]) for i in marg_r], [float(conf[i]) for i in marg_d])
+    for i, r in enumerate(rb.astype(int)):                                # every non-marginal box of either side has a partner within 2 px
+        if i not in marg_r:
+            assert np.abs(bb.astype(int) - r).max(axis=1).min() <= 2, (i, r, float(rconf[i]))
+    for i, d in enumerate(bb.astype(int)):
+        if i not in marg_d:
+            assert np.abs(rb.astype(int) - d).max(axis=1).min() <= 2, (i, d, float(conf[i]))
     assert (np.logical_xor(mask > 127, rmask > 127)).mean() < 0.02
 
 

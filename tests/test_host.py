@@ -380,16 +380,6 @@ def test_conv_w4_wait_counts_cover_every_lds_read(harness):
     assert _w4_check(harness, 4, 8, 0, 7, 0, 0, 2)[0] == 0
 
 
-def test_conv_w8_wait_counts_cover_every_lds_read(harness):
-    """conv_w8 (eight waves: 2 pieces of a double tile and PT pieces of a patch burst per wave) takes its counts from the same queue
-    model with tgw = 2: every instantiated (PT, ring depth) pair, every burst spreading the model allows."""
-    msg = C.create_string_buffer(256)
-    for pt, nbd in ((4, 5), (5, 4), (6, 3)):                 # w4_ring(PT, false)
-        for spread in (0, 1, 2, 3):
-            rc = harness.flope_host_w4_schedule_check_tgw(nbd, pt, spread, 4, 0, 0, 0, 2, msg, 256)
-            assert rc == 0, (pt, nbd, spread, msg.value.decode())
-
-
 def test_conv_w4_queue_model_is_not_stricter_than_the_closed_form(harness):
     """With the cold burst issued whole (spread <= 1) the queue model must reproduce r03's hand-derived counts exactly -- a model
     that over-waits would pass the coverage test and silently cost time."""
