@@ -45,6 +45,15 @@ SIGNATURES = {
     "flope_launch_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_D)]),
     "flope_describe_plan": (_I, [_P, C.c_char_p, _I]),
     "flope_version": (C.c_char_p, []),
+    "flope_engine_geometry": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "flope_frame_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
+    "flope_frame_destroy": (_I, [_P]),
+    "flope_frame_last_error": (C.c_char_p, [_P]),
+    "flope_frame_select": (_I, [_P, _I, _P, _P, _I, _P]),
+    "flope_frame_enqueue": (_I, [_P, _I, _P, _P, _P, _I, _F, C.POINTER(_F), _F, _F, _P]),
+    "flope_frame_finish": (_I, [_P, _I, _P, _I]),
+    "flope_frame_to_poses": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _F, C.POINTER(_F), _F, _F, _P, _I, _P]),
+    "flope_frame_read_boxes": (_I, [_P, _I, _P, _P, _I]),
     "flope_stream_create_cu_mask": (_I, [_I, C.POINTER(C.c_uint32), _I, C.POINTER(_P)]),
     "flope_stream_destroy": (_I, [_I, _P]),
     "flope_yolo_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_P)]),

@@ -358,6 +358,16 @@ extern "C" int flope_stream_destroy(int device_id, void* stream) {
 
 extern "C" const char* flope_version(void) { return "flope_amd 0.1 (gfx950; mfma_f32_16x16x32 bf16/f16; fp32 head)"; }
 
+extern "C" int flope_engine_geometry(flope_handle h, int* max_batch, int* dtype, int* height, int* width, int* device_id) {
+  if (!h) return FLOPE_EINVAL;
+  if (max_batch) *max_batch = h->maxB;
+  if (dtype) *dtype = h->dtype;
+  if (height) *height = h->H;
+  if (width) *width = h->W;
+  if (device_id) *device_id = h->device;
+  return FLOPE_OK;
+}
+
 extern "C" const char* flope_last_error(flope_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
 static int rebuild_plan(flope_engine* e) {

@@ -75,13 +75,22 @@ class PoseResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("flope_amd PoseResNet runs on HIP devices only: move the crop batch to "
                                "'cuda' (there is no CPU fallback)")
-        key = (x.device.index, int(hw[0]), int(hw[1]))
+        return self.engine_for(x.device, hw, int(x.shape[0]))
+
+    def engine_for(self, device, hw, batch: int = 1) -> PoseEngine:
+        """The engine for crops of hw on `device` with room for `batch` crops and the module's current parameters (built on
+        first use, rebuilt when a larger batch arrives, re-loaded after load_state_dict / refresh)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("flope_amd PoseResNet runs on HIP devices only (there is no CPU fallback)")
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        key = (index, int(hw[0]), int(hw[1]))
         slot = self._engines.get(key)
-        if slot is None or slot[0].max_batch < x.shape[0]:
+        if slot is None or slot[0].max_batch < batch:
             if slot is not None:
                 slot[0].close()
-            mb = max(self._max_batch, int(x.shape[0]))
-            slot = [PoseEngine(hw[0], hw[1], mb, self.compute_dtype, x.device, self.backbone_out_dim), -1]
+            mb = max(self._max_batch, int(batch))
+            slot = [PoseEngine(hw[0], hw[1], mb, self.compute_dtype, torch.device("cuda", index), self.backbone_out_dim), -1]
             self._engines[key] = slot
         if slot[1] != self._version:
             slot[0].load_state_dict(self.state_dict())

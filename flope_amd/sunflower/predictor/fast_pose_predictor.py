@@ -114,6 +114,7 @@ class FastPosePredictor:
         frame faster; boxes within 2 px, a candidate within 0.01 of the confidence threshold may flip)."""
         self.device = device
         self.debug = debug
+        self.crop_size = 512                       # fast_pose_predictor.py:115-116
         self.posenet = PoseResNet().to(device)
         self.posenet.load_state_dict(torch.load(posenet_path, weights_only=True))
         print(f"Model loaded: {Path(posenet_path).name}")
@@ -140,15 +141,27 @@ class FastPosePredictor:
         an all-zero mask, where the reference raises on `results[0].masks.data`)"""
         return self._detector(image)
 
+    def _frame_ctx(self, slots: int = 1):
+        """The flope_frame handle behind this predictor's detector (csrc/frame.hip): rebuilt when the PoseResNet engine it
+        borrows was rebuilt (larger batch) or when more slots are needed; parameters re-uploaded after load_state_dict."""
+        eng = self.posenet.engine_for(self.device, (self.crop_size, self.crop_size))
+        ctx = getattr(self, "_fctx", None)
+        if ctx is None or ctx.engine is not eng or ctx.slots < slots:
+            from flope_amd.frame import FramePoses
+            from flope_amd.yolo import MAX_DET
+            if ctx is not None:
+                ctx.close()
+            ctx = self._fctx = FramePoses(eng, self.yolo.frame_h, self.yolo.frame_w, MAX_DET, max(slots, ctx.slots if ctx is not None else 1))
+        return ctx
+
     def get_flower_poses(self, rgb, depth):
         """rgb uint8 [H,W,3], depth uint16 [H,W] (millimetres) -> float64 [N,4,4] | None"""
-        if self.yolo is not None:                  # frame and mask stay on the device between the detector and the crops
+        if self.yolo is not None:
+            # frame, mask and detections stay on the device; everything behind the detector is ONE C call (flope_frame_to_poses:
+            # box selection on the device, a 4-byte count read-back, depth lift, crops, network, Rt, reliability filter)
             det, count, mask_d, frame_d = self.yolo.detect_device(rgb)
             depth_d = upload_depth(depth, torch.device(self.device))   # host copy runs while the GPU is busy with the detector
-            n = int(count.item())
-            bb = det[:n, :4].cpu().numpy().astype(np.int16)           # :55-56
-            return poses_from_detections(self.posenet, rgb, depth, bb, None, self.K, depth_div=1000.0,
-                                         device=self.device, frame_d=frame_d, mask_d=mask_d, depth_d=depth_d)
+            return self._frame_ctx().to_poses(det, count, frame_d, mask_d, depth_d, self.K, depth_div=1000.0)
         bb, mask = self.get_bbox_mask(rgb)
         return poses_from_detections(self.posenet, rgb, depth, bb, mask, self.K, depth_div=1000.0,
                                      device=self.device)
@@ -204,48 +217,39 @@ class FastPosePredictor:
             with torch.cuda.stream(st):
                 st.wait_event(up)
                 dets[t % nd].detect_device(sl["frame"], out=sl["out"], in_place=True)
+                fctx.select(t % NS, sl["out"][0], sl["out"][1])      # box selection on the device, behind the detector; the count goes to pinned memory
                 sl["ready"] = torch.cuda.Event()
                 sl["ready"].record(st)
 
-        def read_boxes(t):
-            sl = slots[t % NS]
-            det, count, _ = sl["out"]
-            with torch.cuda.stream(s_io):               # a stream with nothing queued: waits for this frame's detector only
-                s_io.wait_event(sl["ready"])
-                n = int(count.item())
-                return det[:n, :4].cpu().numpy().astype(np.int16)          # fast_pose_predictor.py:55-56
+        fctx = self._frame_ctx(NS)
 
-        def stage_pose(t, bb):
+        def stage_pose(t):
             sl = slots[t % NS]
             with torch.cuda.stream(s_pose):
                 s_pose.wait_event(sl["ready"])
-                packed = enqueue_poses(self.posenet, sl["shape"], bb, self.K, 1000.0, sl["frame"], sl["out"][2], sl["depth"], device=dev)
+                fctx.enqueue(t % NS, sl["frame"], sl["out"][2], sl["depth"], self.K, 1000.0)   # waits (host) for frame t's box count only
                 sl["pose_done"] = torch.cuda.Event()
                 sl["pose_done"].record(s_pose)
-            return packed
+            return t % NS
 
-        def finish(packed):
-            with torch.cuda.stream(s_pose):
-                return finish_poses(packed)
+        def finish(slot):
+            return fctx.finish(slot)
 
         try:
-            detecting, posing = [], []                 # frame indices in flight per stage (oldest first)
+            detecting, posing = [], []                 # frame indices / frame-handle slots in flight per stage (oldest first)
             for t, (rgb, depth) in enumerate(frames):
                 stage_detect(t, rgb, depth)
                 detecting.append(t)
                 if len(detecting) > nd:                 # the oldest detector ran while nd newer frames were uploaded and queued
-                    u = detecting.pop(0)
-                    bb = read_boxes(u)
-                    if posing:
-                        yield finish(posing.pop(0))     # before new pose work queues up behind it
-                    posing.append(stage_pose(u, bb))
+                    posing.append(stage_pose(detecting.pop(0)))   # its pose work queues up BEHIND the frame before it ...
+                    if len(posing) > 1:
+                        yield finish(posing.pop(0))     # ... whose results the host now waits for (its own event: not the whole stream)
             for u in detecting:
-                bb = read_boxes(u)
-                if posing:
+                posing.append(stage_pose(u))
+                if len(posing) > 1:
                     yield finish(posing.pop(0))
-                posing.append(stage_pose(u, bb))
-            for packed in posing:
-                yield finish(packed)
+            for slot in posing:
+                yield finish(slot)
         finally:
             torch.cuda.synchronize(dev)
             for d, g in zip(dets, prev_graph):

@@ -178,6 +178,8 @@ int flope_profile_timeline(flope_handle h, float* ms_out, int* slice_out, int ca
 int flope_launch_info(flope_handle h, int idx, int batch, char* name, int name_cap, double* flops);
 /* human-readable launch plan (one line per conv: tile config, patch/gather, LDS bytes) */
 int flope_describe_plan(flope_handle h, char* buf, int buflen);
+/* what a handle was created with (max_batch, FLOPE_DT_*, crop height / width, device ordinal); any pointer may be NULL */
+int flope_engine_geometry(flope_handle h, int* max_batch, int* dtype, int* height, int* width, int* device_id);
 /* library / build identification */
 const char* flope_version(void);
 /* A stream restricted to the compute units set in mask[words] (bit i of word i / 32 = CU i in the runtime's enumeration;
@@ -185,6 +187,35 @@ const char* flope_version(void);
  * (FastPosePredictor.iter_flower_poses); any entry point of this library accepts such a stream. */
 int flope_stream_create_cu_mask(int device_id, const uint32_t* mask, int words, void** out_stream);
 int flope_stream_destroy(int device_id, void* stream);
+
+/* ---- frame -> poses behind the detector (r05) ------------------------------------------------
+ * Replaces the body of FastPosePredictor.get_flower_poses AFTER get_bbox_mask (fast_pose_predictor.py:55-56, 60-156): the box
+ * loop (squarify_bb / bb_in_frame, mvg.py:324-351), get_depth_value + get_points3d (:88-106), the crop batch (:108-123), the
+ * network, procrustes_to_rotmat, nullify_yaw_batch and the [N,4,4] assembly (:125-144), the depth-reliability filter (:97-102).
+ * Inputs are the detector's device-resident outputs (flope_yolo_detect: det rows float32 [max_det,8] + count; or any detector's
+ * xyxy rows in that layout), the uint8 BGR frame [H,W,3], the uint8 frame mask [H,W] and the depth image (format / divisor as for
+ * flope_depth_lift).  Three calls per frame so that several frames can be in flight (one `slot` each):
+ *   flope_frame_select   asynchronous: int16 boxes -> squarify -> in-frame filter on the device, in detection order
+ *   flope_frame_enqueue  waits on the host for the NUMBER of surviving boxes (4 bytes: grids are sized by the host), then enqueues
+ *                        everything else and the copy of the results to pinned host memory; returns that number (0: nothing to do)
+ *   flope_frame_finish   waits for the results; poses_out float64 [n,16] row-major 4x4, flowers without reliable depth dropped;
+ *                        returns n (0 = the reference's `None`)
+ * flope_frame_to_poses = the three in sequence on slot 0.  max_boxes bounds the in-frame boxes of one frame (ultralytics' max_det = 300);
+ * a frame with more is refused by flope_frame_enqueue.  More boxes than the engine's max_batch run as several forwards.
+ * The PoseResNet engine must outlive the frame handle and must not run another forward concurrently. */
+typedef struct flope_frame* flope_frame_handle;
+int flope_frame_create(flope_handle pose_engine, int frame_h, int frame_w, int max_boxes, int slots, flope_frame_handle* out);
+int flope_frame_destroy(flope_frame_handle f);
+const char* flope_frame_last_error(flope_frame_handle f);
+int flope_frame_select(flope_frame_handle f, int slot, const float* det_dev, const int32_t* count_dev, int max_det, void* stream);
+int flope_frame_enqueue(flope_frame_handle f, int slot, const uint8_t* frame_dev, const uint8_t* mask_dev, const void* depth_dev,
+                        int depth_format, float depth_div, const float* K4_host, float near_plane, float far_plane, void* stream);
+int flope_frame_finish(flope_frame_handle f, int slot, double* poses_out, int cap);
+int flope_frame_to_poses(flope_frame_handle f, const float* det_dev, const int32_t* count_dev, int max_det, const uint8_t* frame_dev,
+                         const uint8_t* mask_dev, const void* depth_dev, int depth_format, float depth_div, const float* K4_host,
+                         float near_plane, float far_plane, double* poses_out, int cap, void* stream);
+/* test hook: the boxes flope_frame_select kept, as detected (good_host) and squared (sq_host), int32 [n,4] each; returns n */
+int flope_frame_read_boxes(flope_frame_handle f, int slot, int32_t* good_host, int32_t* sq_host, int cap);
 
 /* ---- TransformerEncoder (reference scripts/tf_encoder.py:5-27) -------------
  * Replaces `TransformerEncoder(input_dim, model_dim, out_dim, num_heads, num_layers, ff_dim,

@@ -576,6 +576,84 @@ def test_fast_pose_predictor_end_to_end_vs_oracle(state_dict, tmp_path):
     assert pred.posenet.extract_features(x).shape == (3, 2048)
 
 
+def test_frame_box_selection_on_the_device_is_integer_exact(state_dict):
+    """flope_frame_select (csrc/frame.hip): detector rows -> int16 (numpy astype: truncation) -> squarify_bb -> bb_in_frame, in
+    detection order, on the device == the host loop of fast_pose_predictor.py:65-83 (sunflower.utils.mvg mirrors + the oracle's
+    select_boxes), integer for integer: the hand-derived KATs of SURVEY App. B 5 ([10,20,50,40] -> [10,10,50,50];
+    [0,0,10,5] -> [0,-3,10,7], rejected; xmax == w / ymax == h accepted: the square [w-h,0,w,h]), random rows with fractional coordinates, counts that
+    span several 64-lane ballots (0, 1, 64, 65, 300) and a count above the table (clamped to max_det)."""
+    from flope_amd.engine import PoseEngine
+    from flope_amd.frame import FramePoses
+    from sunflower.predictor.fast_pose_predictor import select_boxes
+    H, W = 480, 640
+    eng = PoseEngine(64, 64, 4, "f16")
+    eng.load_state_dict(state_dict)
+    ctx = FramePoses(eng, H, W, max_boxes=300, slots=2)
+    rng = np.random.default_rng(31)
+    kat = np.array([[10, 20, 50, 40], [0, 0, 10, 5], [W - 40, 100, W, 140], [100, H - 40, 140, H], [3, 3, 4, 200], [W - H, 0, W, H],
+                    [7, 9, 20, 22], [7, 9, 21, 22], [7, 9, 20, 24], [W - 11, 10, W - 1, 31]], dtype=np.float32)
+    for count in (0, 1, 10, 64, 65, 300, 301):
+        det = np.zeros((300, 8), np.float32)
+        x0 = rng.uniform(0, W - 2, 300); y0 = rng.uniform(0, H - 2, 300)
+        det[:, 0] = x0; det[:, 1] = y0
+        det[:, 2] = np.minimum(x0 + rng.uniform(1, 220, 300), W); det[:, 3] = np.minimum(y0 + rng.uniform(1, 220, 300), H)
+        det[:10, :4] = kat
+        det[:, 4] = rng.uniform(0.25, 1, 300)
+        n = min(count, 300)
+        d_dev = torch.from_numpy(det).cuda()
+        c_dev = torch.tensor([count], dtype=torch.int32, device="cuda")
+        ctx.select(1, d_dev, c_dev)
+        good, sq = ctx.read_boxes(1)
+        bb = det[:n, :4].astype(np.int16)                                        # fast_pose_predictor.py:55-56
+        _, sq_ref, good_ref = select_boxes(bb, (H, W, 3))
+        assert np.array_equal(good, good_ref.astype(np.int32)) and np.array_equal(sq, sq_ref.astype(np.int32)), count
+        _, sq_o, good_o = P.select_boxes(bb, (H, W, 3))                          # the oracle's statement of the same loop
+        assert np.array_equal(good, np.asarray(good_o, dtype=np.int32).reshape(-1, 4)) and np.array_equal(sq, np.asarray(sq_o, dtype=np.int32).reshape(-1, 4))
+        if count >= 10:
+            assert [10, 10, 50, 50] in sq.tolist() and [0, -3, 10, 7] not in sq.tolist() and [W - H, 0, W, H] in sq.tolist()
+    ctx.close(); eng.close()
+
+
+def test_frame_to_poses_is_the_host_path_bit_for_bit(state_dict, tmp_path):
+    """flope_frame_to_poses (one C call behind the detector: device-side box selection, count read-back, depth lift, crops,
+    network, Rt, reliability filter) returns exactly the float64 poses of the r01-r04 host path (`poses_from_detections`: numpy box
+    loop + one ctypes call per kernel), for detections given as the detector would leave them on the device -- including the
+    frame whose only box leaves the frame (None) and the one without reliable depth (None)."""
+    import yaml
+    from flope_amd.frame import FramePoses
+    from sunflower.predictor.fast_pose_predictor import FastPosePredictor, poses_from_detections, upload_depth
+    rgb, mask, depth, boxes = _scene(24)
+    ckpt, intr = tmp_path / "posenet.pth", tmp_path / "intrinsics.yaml"
+    torch.save(state_dict, ckpt)
+    intr.write_text(yaml.safe_dump(dict(fx=600.0, fy=600.0, cx=320.0, cy=240.0, h=480, w=640)))
+    pred = FastPosePredictor("cuda", lambda img: (boxes, mask), str(ckpt), str(intr))
+    eng = pred.posenet.engine_for("cuda", (512, 512))
+    ctx = FramePoses(eng, 480, 640, max_boxes=300)
+    frame_d, mask_d, depth_d = torch.from_numpy(rgb).cuda(), torch.from_numpy(mask).cuda(), upload_depth(depth, torch.device("cuda"))
+    for sel in (boxes, boxes[-2:-1], boxes[-1:], boxes[:0]):
+        det = torch.zeros((300, 8), dtype=torch.float32, device="cuda")
+        if len(sel):
+            det[:len(sel), :4] = torch.from_numpy(sel.astype(np.float32) + 0.4).cuda()      # (fractions: the int16 cast truncates)
+        count = torch.tensor([len(sel)], dtype=torch.int32, device="cuda")
+        got = ctx.to_poses(det, count, frame_d, mask_d, depth_d, pred.K)
+        ref = poses_from_detections(pred.posenet, rgb, depth, sel, mask, pred.K, depth_div=1000.0, device="cuda")
+        assert (got is None) == (ref is None)
+        if ref is not None:
+            assert got.dtype == np.float64 and np.array_equal(got, ref) and got.shape[0] >= 3
+    # more boxes than the engine's batch: several forwards behind one call (engine max_batch 64: 150 boxes = 3 forwards)
+    many = np.tile(boxes[:6], (25, 1))
+    det = torch.zeros((300, 8), dtype=torch.float32, device="cuda")
+    det[:150, :4] = torch.from_numpy(many.astype(np.float32)).cuda()
+    got = ctx.to_poses(det, torch.tensor([150], dtype=torch.int32, device="cuda"), frame_d, mask_d, depth_d, pred.K)
+    one = ctx.to_poses(det, torch.tensor([6], dtype=torch.int32, device="cuda"), frame_d, mask_d, depth_d, pred.K)
+    # (B = 6 sums K in split-K order, B = 64 does not: equal up to float32 summation order in the 16-bit trunk; translations exact)
+    rep = np.tile(one, (25, 1, 1))
+    assert got.shape == (150, 4, 4) and np.abs(got - rep).max() <= 2e-3 and np.array_equal(got[:, :, 3], rep[:, :, 3])
+    with pytest.raises(RuntimeError, match="select"):
+        ctx.enqueue(0, frame_d, mask_d, depth_d, pred.K)                             # call order
+    ctx.close()
+
+
 def test_error_paths(state_dict):
     from flope_amd.engine import PoseEngine
     e = PoseEngine(64, 64, 2, "f16")

@@ -39,7 +39,9 @@ def main_yolo(tmp, ckpt, intr):
     torch.save({**synthetic_yolo_state_dict(0), "imgsz": torch.tensor(1280)}, yolo_f)
     rgb = synthetic_frame(0)
     depth = (400 + np.random.default_rng(0).normal(0, 4, rgb.shape[:2])).astype(np.uint16)
-    pred = FastPosePredictor("cuda", yolo_f, ckpt, intr)
+    ydt = os.environ.get("YOLO_DTYPE", "f32")                        # r05: the exact-float32 detector is the predictor's default
+    pred = FastPosePredictor("cuda", yolo_f, ckpt, intr, yolo_dtype=ydt)
+    print(f"detector dtype: {ydt}", flush=True)
     for _ in range(3):
         Rt = pred.get_flower_poses(rgb, depth)
     torch.cuda.synchronize()
