@@ -46,7 +46,7 @@ extern "C" int flope_stem_pool_init();
 extern "C" void flope_stem_pool_set_dbg(void* ptr);
 #endif
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
-                                      const void* w, const float* bias, void* out, int dtype, int persist_blocks, void* stream);
+                                      const void* w, const void* w2, const float* bias, void* out, int dtype, int persist_blocks, void* stream);
 
 using namespace flope_host;
 
@@ -96,7 +96,7 @@ struct flope_engine {
   int sHip = 0, sWip = 0, Hs = 0, Ws = 0, stem_tiles = 0, stem_rows = 0;
   size_t stem_lds = 0;
   void* stem_in = nullptr; size_t stem_in_bytes = 0;
-  void* stem_w = nullptr; float* stem_w_naive = nullptr; float* stem_bias = nullptr;
+  void* stem_w = nullptr; void* stem_w2 = nullptr; float* stem_w_naive = nullptr; float* stem_bias = nullptr;   // stem_w2: per-wave fragment order (stem_pool_r_kernel)
   std::vector<Buf> bufs;             // 0 stem_out, 1 pool, then per block: mid, [ds], out
   std::vector<Conv> convs;
   int stage_buf[10];                 // FLOPE_STAGE_* (0..9) -> buffer index
@@ -104,7 +104,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_stem_r = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -518,7 +518,7 @@ extern "C" int flope_destroy(flope_handle e) {
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
   for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.bias_fused) hipFree(c.bias_fused); }
-  void* singles[] = {e->stem_in, e->stem_w, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
+  void* singles[] = {e->stem_in, e->stem_w, e->stem_w2, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
@@ -552,6 +552,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "w4mt")) { prev = e->opt_w4mt; e->opt_w4mt = (value >= 5 && value <= 8) ? value : 0; return prev; }   // conv_w4 tile height: 0 = per launch, 5..8 = 160..256 pixels (where the shape has that instantiation)
   else if (!strcmp(name, "fc2_k4")) { prev = e->opt_fc2_k4; e->opt_fc2_k4 = value != 0; return prev; }            // fc_rot: K split over the four waves of a workgroup per image
   else if (!strcmp(name, "ksplit")) { prev = e->opt_ksplit; e->opt_ksplit = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }   // 2: always the largest split (r02a rule)
+  else if (!strcmp(name, "stem_r")) { prev = e->opt_stem_r; e->opt_stem_r = value != 0; return prev; }   // 1: the register-weight stem (three workgroups per CU, r05); 0: the r02 forms (stem_persist)
   else if (!strcmp(name, "stem_persist")) { prev = e->opt_stem_persist; e->opt_stem_persist = value < 0 ? 0 : (value > 2 ? 2 : value); return prev; }
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
@@ -596,7 +597,10 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
   if ((rc = fold(e, ts, "base.conv1", "base.bn1", 64, 3, 7, &wf, &bf)) != 0) return rc;
   if ((rc = upload(e, bf, (void**)&e->stem_bias)) != 0) return rc;
   if (e->dtype == FLOPE_DT_F32) { if ((rc = upload(e, naive_layout(wf, 64, 3, 7), (void**)&e->stem_w_naive)) != 0) return rc; }
-  else { if ((rc = upload(e, pack_stem(wf, e->dtype), &e->stem_w)) != 0) return rc; }
+  else {
+    if ((rc = upload(e, pack_stem(wf, e->dtype), &e->stem_w)) != 0) return rc;
+    if ((rc = upload(e, pack_stem_frag(wf, e->dtype), &e->stem_w2)) != 0) return rc;
+  }
   for (Conv& c : e->convs) {
     if ((rc = fold(e, ts, c.name, c.bn, c.cout, c.cin, c.k, &wf, &bf)) != 0) return rc;
     if ((rc = upload(e, bf, (void**)&c.bias)) != 0) return rc;
@@ -668,11 +672,14 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
 #ifdef FLOPE_STAG_DBG
     flope_stem_pool_set_dbg(((e->opt_dbg & 64) && e->split_ws) ? (void*)(e->split_ws + (size_t)30 * (kDbgRegion / 4)) : nullptr);
 #endif
-    K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w,
+    // r05: the register-weight form (weights in VGPRs, 51 KB of LDS: three workgroups per CU) where the option asks for it; else the
+    // r02 forms -- persistent where that measured faster (same-run A/B at B = 256: 224 x 224 crops +2.7 % on the step; 512 x 512
+    // crops -7 % on the kernel.  stem_persist: 1 = auto, 2 = always, 0 = never)
+    const bool stem_r = e->opt_stem_r && e->stem_w2;
+    K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w, stem_r ? e->stem_w2 : nullptr,
                                                    e->stem_bias, bp.ptr, dt,
-                                                   // persistent form where it measured faster (r02, same-run A/B at B = 256): 224 x 224 crops
-                                                   // +2.7 % on the step; 512 x 512 crops -7 % on the kernel.  1 = auto, 2 = always, 0 = never
-                                                   (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
+                                                   stem_r ? 3 * e->num_cus
+                                                          : (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
                                                    stream));
   } else {
     SMARK();

@@ -154,6 +154,21 @@ inline std::vector<uint16_t> pack_stem(const std::vector<float>& wf, int dtype) 
   return out;
 }
 
+// stem weights for stem_pool_r_kernel (r05): wave w owns channels 16 w .. 16 w + 15 and keeps its seven A fragments in registers:
+// [4 waves][7 ky][64 lanes][8]  <-  W[16 w + (lane & 15)][ky][k = 8 (lane >> 4) + j],  k = kx * 4 + c  (zero for kx = 7 or c = 3)
+inline std::vector<uint16_t> pack_stem_frag(const std::vector<float>& wf, int dtype) {
+  std::vector<uint16_t> out((size_t)4 * 7 * 64 * 8, cvt16(0.f, dtype));
+  for (int w = 0; w < 4; ++w)
+    for (int ky = 0; ky < 7; ++ky)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int co = 16 * w + (lane & 15), kk = 8 * (lane >> 4) + j, kx = kk >> 2, c = kk & 3;
+          const float v = (kx < 7 && c < 3) ? wf[(((size_t)co * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
+          out[(((size_t)w * 7 + ky) * 64 + lane) * 8 + j] = cvt16(v, dtype);
+        }
+  return out;
+}
+
 inline std::vector<float> naive_layout(const std::vector<float>& wf, int cout, int cin, int k) {
   std::vector<float> out((size_t)cout * cin * k * k);
   for (int co = 0; co < cout; ++co)

@@ -23,6 +23,7 @@ struct StemPoolP {
   const void* x;       // crop batch in in_format
   void* out;           // padded NHWC [B][Hq+2][Wq+2][64]
   const void* w;       // packed [7 ky][64 rows][32 k] LDS image (host_pack.h pack_stem)
+  const void* w2;      // the same weights in per-wave A-fragment order (host_pack.h pack_stem_frag): stem_pool_r_kernel
   const float* bias;   // [64]
   int in_format;       // FLOPE_IN_*
   int B, H, W;         // crop size
@@ -497,6 +498,237 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 #undef ST_PH
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Register-weight form (r05; VERDICT r4 item 5: "change the decomposition").  What the persistent kernel above leaves on the table
+// (r03 / r04 stamps): a tile is a chain of phases -- MFMA 4.9 k cycles for 2.2 k of matrix work, window + ReLU + conv-output
+// writes 2.6 k, pool 2.2 k -- on a CU that holds only TWO workgroups (78 KB of LDS, 210 registers), so whenever both are outside
+// their MFMA phase the matrix pipe idles; and every pool read was a 2-way bank conflict (two pooled pixels of a 16-lane group sit
+// two conv columns apart = two 128-byte rows of the same bank half: the 25 % replays the counters have shown since r02).
+//   * The OUTPUT CHANNELS are split over the waves instead of the pixel tiles: wave w owns channels 16 w .. 16 w + 15 and keeps
+//     its seven weight fragments (7 ky x 16 B per lane) in REGISTERS for the life of the workgroup -- no weight image in LDS
+//     (28 KB), no weight reads in the loop (4 of every 9 fragment reads).  Every wave walks all 19 pixel tiles of the 17 x 17
+//     conv region, ONE tile at a time: 7 fragment reads (one base register + immediate offsets), 7 MFMAs on one accumulator
+//     tile, ReLU + pack, one 8-byte LDS write -- 4 live accumulator registers instead of 80.
+//   * LDS = 13 KB window + 39 KB conv outputs = 51 KB, ~130 registers: THREE workgroups per CU.
+//   * Conv outputs in LDS: pixel (row t, column c) at slot t * 18 + pi(c), pi = evens then odds, so that the two conv columns a
+//     16-lane pool read touches (c and c + 2) fall into different bank halves; 16-byte chunk cg of a pixel at cg ^ k(c) with k a
+//     function of the column only (tile-independent write offsets), chosen so that the 16 pixels of a write instruction cover 16
+//     distinct bank groups.  Pool reads and conv-output writes are conflict-free (column 16's once-per-tile writes: 2-way).
+// Same arithmetic per output as the kernels above (bias as the first MFMA's C operand, ky = 0 .. 6 in order, k = kx * 4 + c):
+// bit-identical (tests/test_gpu_parity.py).
+__device__ __forceinline__ int stem_pi(int c) { return (c >> 1) + (c & 1) * 9; }
+__device__ __forceinline__ int stem_key(int c, int t) { return c == 16 ? (t & 7) : (((c & 1) << 2) + ((c >> 2) & 3)); }
+
+template <typename T, int FMT>
+__global__ __launch_bounds__(256, 3) void stem_pool_r_kernel(const StemPoolP p) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int PR = 39, PC = 42;
+  constexpr int P_BYTES = ((PR * PC * 8 + 15) / 16) * 16;
+  constexpr int CR = 17, CS = 18, NI = 7;                     // conv region 17 x 17; 18 pixel slots per conv row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ps = smem;
+  char* const Cs = smem + P_BYTES;                            // [17][18 slots][64 ch] conv outputs
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int G = gridDim.x, total = p.B * p.tiles_y * p.tiles_x;
+  const int lb = xcd_remap(blockIdx.x, G);
+
+  // this wave's weights: seven fragments, straight from global memory in fragment order (one contiguous KiB per wave-load)
+  frag wf[7];
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) wf[ky] = *(const frag*)((const char*)p.w2 + ((size_t)(wave * 7 + ky) * 64 + lane) * 16);
+  const f32x4 b4 = *(const f32x4*)(p.bias + wave * 16 + g * 4);
+
+  // ---- staging geometry of this thread (tile independent): window column c, rows r0 + 6k   (as stem_pool_persist_kernel)
+  const bool stager = tid < 6 * PC;
+  const int st = min(tid, 6 * PC - 1);
+  const int r0 = st / PC, c = st - r0 * PC;
+  constexpr int estep = FMT == 0 ? 1 : 3;
+  const size_t img_elems = (size_t)3 * p.H * p.W;
+  const int plane = p.H * p.W;
+  unsigned raw[NI][FMT == 0 ? 3 : 2];
+  unsigned okmask = 0, rowmask = 0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) if (r0 + 6 * k < PR) rowmask |= 1u << k;
+  auto tile_origin = [&](int tile, int& tx, int& ty, int& img) {
+    const int q = fastdiv(tile, p.mg_tx, p.sh_tx);
+    tx = tile - q * p.tiles_x;
+    img = fastdiv(q, p.mg_ty, p.sh_ty);
+    ty = q - img * p.tiles_y;
+  };
+  auto issue_loads = [&](int tile) {
+    int tx, ty, img;
+    tile_origin(tile, tx, ty, img);
+    const int py0 = 2 * (2 * (ty * 8) - 1) - 3, px0 = 2 * (2 * (tx * 8) - 1) - 3;
+    const int x = px0 + c;
+    int off[NI];
+    if (py0 >= 0 && py0 + PR <= p.H && px0 >= 0 && px0 + PC <= p.W) {
+      okmask = rowmask;
+      const int rs = 6 * p.W * estep;
+      off[0] = ((py0 + r0) * p.W + x) * estep;
+#pragma unroll
+      for (int k = 1; k < NI; ++k) off[k] = off[k - 1] + rs;
+      if (r0 + 6 * (NI - 1) >= PR) off[NI - 1] = off[NI - 2];
+    } else {
+      const bool okx = x >= 0 && x < p.W;
+      const int xoffs = min(max(x, 0), p.W - 1) * estep;
+      okmask = 0;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int r = r0 + 6 * k, y = py0 + r;
+        if (okx && r < PR && y >= 0 && y < p.H) okmask |= 1u << k;
+        off[k] = min(max(y, 0), p.H - 1) * p.W * estep + xoffs;
+      }
+    }
+    if constexpr (FMT == 0) {
+      const float* s = (const float*)p.x + (size_t)img * img_elems;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        raw[k][0] = __builtin_bit_cast(unsigned, s[off[k]]); raw[k][1] = __builtin_bit_cast(unsigned, s[off[k] + plane]);
+        raw[k][2] = __builtin_bit_cast(unsigned, s[off[k] + 2 * plane]);
+      }
+    } else if constexpr (FMT == 3) {
+      const unsigned char* s = (const unsigned char*)p.x + (size_t)img * img_elems;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        unsigned short w01; __builtin_memcpy(&w01, s + off[k], 2);
+        raw[k][0] = w01; raw[k][1] = s[off[k] + 2];
+      }
+    } else {
+      const unsigned short* s = (const unsigned short*)p.x + (size_t)img * img_elems;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        unsigned w01; __builtin_memcpy(&w01, s + off[k], 4);
+        raw[k][0] = w01; raw[k][1] = s[off[k] + 2];
+      }
+    }
+  };
+  auto write_window = [&]() {
+    if (!stager) return;
+    constexpr bool same = (FMT == 1) == std::is_same<T, bf16_t>::value;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      u32x2 px;
+      if constexpr (FMT == 0)
+        px = pack4<T>(__builtin_bit_cast(float, raw[k][0]), __builtin_bit_cast(float, raw[k][1]), __builtin_bit_cast(float, raw[k][FMT == 0 ? 2 : 0]));
+      else if constexpr (FMT == 3)
+        px = pack4<T>((float)(raw[k][0] & 0xffu) / 255.0f, (float)(raw[k][0] >> 8) / 255.0f, (float)raw[k][1] / 255.0f);
+      else if constexpr (same)
+        px = u32x2{raw[k][0], raw[k][1]};
+      else if constexpr (FMT == 1)
+        px = pack4<T>(to_f32(__builtin_bit_cast(bf16_t, (unsigned short)(raw[k][0] & 0xffffu))), to_f32(__builtin_bit_cast(bf16_t, (unsigned short)(raw[k][0] >> 16))),
+                      to_f32(__builtin_bit_cast(bf16_t, (unsigned short)raw[k][1])));
+      else
+        px = pack4<T>(to_f32(__builtin_bit_cast(f16_t, (unsigned short)(raw[k][0] & 0xffffu))), to_f32(__builtin_bit_cast(f16_t, (unsigned short)(raw[k][0] >> 16))),
+                      to_f32(__builtin_bit_cast(f16_t, (unsigned short)raw[k][1])));
+      if (r0 + 6 * k < PR) *(u32x2*)(Ps + (tid + 6 * PC * k) * 8) = ((okmask >> k) & 1u) ? px : u32x2{0u, 0u};
+    }
+  };
+
+  // ---- tile-independent LDS offsets of this lane
+  // fragment reads: tile t < 17 = conv row t, columns r16 (+ t * 2 PC 8 as an immediate); tile 17 = column 16 of rows r16;
+  // tile 18 = the corner (16, 16): every lane reads it, lane r16 == 0 owns it
+  const int xb_row = (2 * r16) * 8 + g * 16;
+  const int xb_col = (2 * r16 * PC + 2 * (CR - 1)) * 8 + g * 16;
+  const int xb_cor = (2 * (CR - 1) * PC + 2 * (CR - 1)) * 8 + g * 16;
+  // conv-output writes: this lane's 4 channels 16 w + 4 g .. of pixel (t, c): 8-byte granule (g & 1) of chunk cg = 2 w + (g >> 1)
+  const int cgw = 2 * wave + (g >> 1), subw = (g & 1) * 8;
+  const int cw_row = stem_pi(r16) * 128 + ((cgw ^ stem_key(r16, 0)) << 4) + subw;                       // + t * CS * 128
+  const int cw_col = (r16 * CS + stem_pi(CR - 1)) * 128 + ((cgw ^ stem_key(CR - 1, r16)) << 4) + subw;
+  const int cw_cor = ((CR - 1) * CS + stem_pi(CR - 1)) * 128 + ((cgw ^ stem_key(CR - 1, CR - 1)) << 4) + subw;
+  // pool reads: the nine conv outputs under each of this thread's two items (pooled pixel, 8-channel group)
+  int pro[2][9];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = tid + it * 256, cg = i & 7, pp = i >> 3, pr = pp >> 3, pc = pp & 7;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int qr = 2 * pr + t / 3, qc = 2 * pc + t % 3;
+      pro[it][t] = (qr * CS + stem_pi(qc)) * 128 + ((cg ^ stem_key(qc, qr)) << 4);
+    }
+  }
+
+  int tile = lb;
+  if (tile < total) { issue_loads(tile); write_window(); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (; tile < total; tile += G) {
+    int tx, ty, img;
+    tile_origin(tile, tx, ty, img);
+    const int cr0 = 2 * (ty * 8) - 1, cc0 = 2 * (tx * 8) - 1;
+    const bool has_next = tile + G < total;
+    if (has_next) issue_loads(tile + G);           // in flight during the MFMA phase
+    asm volatile("" ::: "memory");
+    // Conv positions outside the feature map (the -1 row / column of top / left tiles, the tail of a ragged last tile) must be 0:
+    // neutral for a max over ReLU outputs.  Branch-free -- a branch per pixel tile cuts the stream into basic blocks and the
+    // compiler then issues every fragment read right in front of its MFMA (r05 first version: 64+ cycles of LDS latency exposed per
+    // tile): the row test is wave-uniform per tile, the column test per lane and tile-independent -> one 64-bit lane mask per tile.
+    const unsigned long long colmask = __ballot(cc0 + r16 >= 0 && cc0 + r16 < p.Ws);
+    const unsigned long long c16mask = (cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws) ? __ballot(cr0 + r16 >= 0 && cr0 + r16 < p.Hs) : 0ull;
+    const bool corner_ok = cr0 + CR - 1 >= 0 && cr0 + CR - 1 < p.Hs && cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws;
+    const unsigned long long lanebit = 1ull << lane;
+    auto finish = [&](const f32x4 a_, unsigned long long okm_, int cw_, bool own_) {      // ReLU + pack, one 8-byte write
+      u32x2 o_ = u32x2{pk_relu16<T>(pack2<T>(a_[0], a_[1])), pk_relu16<T>(pack2<T>(a_[2], a_[3]))};
+      if (!(okm_ & lanebit)) o_ = u32x2{0u, 0u};
+      if (own_) *(u32x2*)(Cs + cw_) = o_;
+    };
+    // The 17 row tiles share window rows: conv row t reads rows 2 t .. 2 t + 6, so every row fragment is read ONCE (39 reads, not
+    // 119), two new ones per tile, issued a whole tile ahead of their first MFMA; a tile's epilogue runs behind the NEXT tile's MFMAs
+    // (its accumulators have long landed).  The column tile and the corner (7 reads each) go first.
+    frag xr[PR];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) xr[r] = *(const frag*)(Ps + xb_row + r * (PC * 8));
+    f32x4 a_col, a_cor, a_prev;
+    {
+      frag xc[7], xk[7];
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) { xc[ky] = *(const frag*)(Ps + xb_col + ky * (PC * 8)); xk[ky] = *(const frag*)(Ps + xb_cor + ky * (PC * 8)); }
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) a_col = Elem<T>::mfma(wf[ky], xc[ky], ky == 0 ? b4 : a_col);
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) a_cor = Elem<T>::mfma(wf[ky], xk[ky], ky == 0 ? b4 : a_cor);
+    }
+#pragma unroll
+    for (int t = 0; t < CR; ++t) {
+      if (2 * t + 7 < PR) xr[2 * t + 7] = *(const frag*)(Ps + xb_row + (2 * t + 7) * (PC * 8));
+      if (2 * t + 8 < PR) xr[2 * t + 8] = *(const frag*)(Ps + xb_row + (2 * t + 8) * (PC * 8));
+      __builtin_amdgcn_sched_barrier(0);             // the reads stay HERE, a tile ahead of their first use (left alone, the scheduler sinks them in front of it)
+      f32x4 a_;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) a_ = Elem<T>::mfma(wf[ky], xr[2 * t + ky], ky == 0 ? b4 : a_);
+      if (t == 0) { finish(a_col, c16mask, cw_col, true); finish(a_cor, corner_ok ? ~0ull : 0ull, cw_cor, r16 == 0); }
+      else finish(a_prev, (cr0 + t - 1 >= 0 && cr0 + t - 1 < p.Hs) ? colmask : 0ull, cw_row + (t - 1) * (CS * 128), true);
+      a_prev = a_;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    finish(a_prev, (cr0 + CR - 1 >= 0 && cr0 + CR - 1 < p.Hs) ? colmask : 0ull, cw_row + (CR - 1) * (CS * 128), true);
+    __syncthreads();                               // conv outputs complete; Ps is free
+    if (has_next) write_window();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + it * 256;
+      const int cg = i & 7, pp = i >> 3;
+      const int pr = pp >> 3, pc = pp & 7;
+      const int oy = ty * 8 + pr, ox = tx * 8 + pc;
+      if (oy >= p.Hq || ox >= p.Wq) continue;
+      u32x4 o = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const u32x4 v = *(const u32x4*)(Cs + pro[it][t]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
+      }
+      char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
+      *(u32x4*)dst = o;
+    }
+    __syncthreads();                               // pool done with Cs, window written: next tile
+  }
+}
+
 // (r02 also built a register-pool form -- 7 x 7 pooled pixels per workgroup, pooling by v_pk_max across accumulator tiles and DPP
 // row shifts, no conv-output buffer in LDS, three workgroups per CU.  Bit-identical and slower: 197 vs 150 us at 224 x 224, 983 vs
 // 697 us at 512 x 512 (+30 % MFMAs for the conv rows computed twice).  Removed in r04; numbers in DESIGN.md 4.2.)
@@ -507,26 +739,28 @@ extern "C" int flope_stem_pool_init() {
   hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)stem_pool_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-#define PA(T_, F_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#define PA(T_, F_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_persist_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+                   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_pool_r_kernel<T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   PA(bf16_t, 0) PA(bf16_t, 1) PA(bf16_t, 2) PA(bf16_t, 3) PA(f16_t, 0) PA(f16_t, 1) PA(f16_t, 2) PA(f16_t, 3)
 #undef PA
   return (int)e;
 }
 
 // persist_blocks > 0: a persistent kernel on that many workgroups; 0: one workgroup per tile.
+// w2 != nullptr (and persist_blocks > 0): the register-weight form (stem_pool_r_kernel; persist_blocks should be 3 per CU).
 #ifdef FLOPE_STAG_DBG
 static unsigned long long* g_stem_dbg = nullptr;
 extern "C" void flope_stem_pool_set_dbg(void* ptr) { g_stem_dbg = (unsigned long long*)ptr; }
 #endif
 
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq,
-                                      int Wq, const void* w, const float* bias, void* out, int dtype, int persist_blocks,
+                                      int Wq, const void* w, const void* w2, const float* bias, void* out, int dtype, int persist_blocks,
                                       void* stream) {
   StemPoolP p;
 #ifdef FLOPE_STAG_DBG
   p.dbg = g_stem_dbg;
 #endif
-  p.x = x; p.out = out; p.w = w; p.bias = bias; p.in_format = in_format;
+  p.x = x; p.out = out; p.w = w; p.w2 = w2; p.bias = bias; p.in_format = in_format;
   p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws_; p.Hq = Hq; p.Wq = Wq;
   p.tiles_y = (Hq + 7) / 8; p.tiles_x = (Wq + 7) / 8;
   flope_host::fastdiv_magic((unsigned)p.tiles_x, &p.mg_tx, &p.sh_tx);
@@ -535,6 +769,14 @@ extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H
   if (persist_blocks > 0) {
     const int total = B * p.tiles_y * p.tiles_x;
     const dim3 pgrid(persist_blocks < total ? persist_blocks : total);
+    if (w2) {
+      const size_t rlds = ((39 * 42 * 8 + 15) / 16) * 16 + 17 * 18 * 128;
+#define RL(T_, F_) hipLaunchKernelGGL((stem_pool_r_kernel<T_, F_>), pgrid, block, rlds, (hipStream_t)stream, p)
+      if (dtype == 0) { if (in_format == 0) RL(bf16_t, 0); else if (in_format == 1) RL(bf16_t, 1); else if (in_format == 2) RL(bf16_t, 2); else RL(bf16_t, 3); }
+      else            { if (in_format == 0) RL(f16_t, 0); else if (in_format == 1) RL(f16_t, 1); else if (in_format == 2) RL(f16_t, 2); else RL(f16_t, 3); }
+#undef RL
+      return (int)hipGetLastError();
+    }
     const size_t plds = 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16 + 17 * 17 * 128;
 #define PL(T_, F_) hipLaunchKernelGGL((stem_pool_persist_kernel<T_, F_>), pgrid, block, plds, (hipStream_t)stream, p)
     if (dtype == 0) { if (in_format == 0) PL(bf16_t, 0); else if (in_format == 1) PL(bf16_t, 1); else if (in_format == 2) PL(bf16_t, 2); else PL(bf16_t, 3); }

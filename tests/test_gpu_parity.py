@@ -140,6 +140,34 @@ def test_conflict_free_patch_image_and_4_wave_kernel_do_not_change_a_bit(state_d
     assert _rel(outs[0][0], emu["r9"]) <= (2e-3 if dtype == "f16" else 1e-2)
 
 
+@pytest.mark.parametrize("H,W,B,dtype", [(224, 224, 9, "f16"), (224, 224, 3, "bf16"), (96, 80, 3, "f16"), (65, 71, 2, "f16"), (512, 512, 2, "f16")])
+def test_register_weight_stem_does_not_change_a_bit(state_dict, H, W, B, dtype):
+    """stem_pool_r_kernel (r05, default: output channels split over the waves, weights in registers, one pixel tile at a time, three
+    workgroups per CU, conflict-free conv-output image) against the r02 forms (option stem_r = 0: persistent and one-tile-per-
+    workgroup kernels): the same MFMAs in the same order per output -> the pooled map and everything behind it bit for bit, for
+    every input format (float32 NCHW, 16-bit NHWC of either type, uint8 NHWC), ragged last tiles (65 x 71 -> 17 x 18 pooled) and
+    tiles on all four image borders."""
+    torch.manual_seed(31)
+    x = (torch.rand(B, 3, H, W) * 255).round() / 255
+    nh = x.permute(0, 2, 3, 1).contiguous()
+    inputs = [x.cuda(), nh.to(TDT[dtype]).cuda(), nh.to(torch.float16 if dtype == "bf16" else torch.bfloat16).cuda(), (nh * 255).round().to(torch.uint8).cuda()]
+    outs = []
+    for opts in (dict(stem_r=1), dict(stem_r=0, stem_persist=2), dict(stem_r=0, stem_persist=0)):
+        e = _engine(state_dict, H, W, B, dtype, **opts)
+        row = []
+        for xi in inputs:
+            r9, R = e.forward(xi)
+            row.append([r9.cpu(), R.cpu(), e.read_stage("pool", B).cpu()])
+        outs.append(row)
+        e.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
+    emu = O.forward_stages_emulated(state_dict, x, TDT[dtype])
+    assert _rel(outs[0][0][2], emu["pool"]) <= (2e-3 if dtype == "f16" else 1e-2)
+
+
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
 def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg):
     """BASELINE cfg1 inputs (16 seeded 224x224 crops) against the committed goldens."""
