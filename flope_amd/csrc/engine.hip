@@ -42,6 +42,7 @@ extern "C" int flope_conv_gstag_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_conv_stag_launch(const ConvP* p, int dtype, int grid_blocks, size_t lds, void* stream);
 extern "C" int flope_conv_split_finalize_launch(const ConvP* p, int dtype, void* stream);
 extern "C" int flope_stem_pool_init();
+extern "C" int flope_stem_pool_r_blocks_per_cu();
 #ifdef FLOPE_STAG_DBG
 extern "C" void flope_stem_pool_set_dbg(void* ptr);
 #endif
@@ -678,7 +679,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
     const bool stem_r = e->opt_stem_r && e->stem_w2;
     K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w, stem_r ? e->stem_w2 : nullptr,
                                                    e->stem_bias, bp.ptr, dt,
-                                                   stem_r ? 3 * e->num_cus
+                                                   stem_r ? flope_stem_pool_r_blocks_per_cu() * e->num_cus
                                                           : (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,
                                                    stream));
   } else {

@@ -510,8 +510,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 //     (28 KB), no weight reads in the loop (4 of every 9 fragment reads).  Every wave walks all 19 pixel tiles of the 17 x 17
 //     conv region, ONE tile at a time: 7 fragment reads (one base register + immediate offsets), 7 MFMAs on one accumulator
 //     tile, ReLU + pack, one 8-byte LDS write -- 4 live accumulator registers instead of 80.
-//   * LDS = 13 KB window + 39 KB conv outputs = 51 KB, ~130 registers: THREE workgroups per CU.
-//   * Conv outputs in LDS: pixel (row t, column c) at slot t * 18 + pi(c), pi = evens then odds, so that the two conv columns a
+//   * VERTICAL pooling happens in registers (a lane holds one conv column in every row tile): only the 8 pooled rows go to LDS.
+//   * LDS = 13 KB window + 18 KB pooled rows + 2 KB conv column 16 = 34 KB, 141 registers: THREE workgroups per CU (a fourth fits
+//     with 128 registers and six spills and measured the same: 121.5 vs 118.4 us; so did static wave priorities by co-resident
+//     workgroup or by hardware wave slot, built to break a suspected convoy of the MFMA phases: 123.6 / 124.1 / 128.7 us).
+//   * Pooled rows in LDS: pixel (pooled row pr, column c) at slot pr * 18 + pi(c), pi = evens then odds, so that the two conv columns a
 //     16-lane pool read touches (c and c + 2) fall into different bank halves; 16-byte chunk cg of a pixel at cg ^ k(c) with k a
 //     function of the column only (tile-independent write offsets), chosen so that the 16 pixels of a write instruction cover 16
 //     distinct bank groups.  Pool reads and conv-output writes are conflict-free (column 16's once-per-tile writes: 2-way).
@@ -520,15 +523,19 @@ __global__ __launch_bounds__(256, 2) void stem_pool_persist_kernel(const StemPoo
 __device__ __forceinline__ int stem_pi(int c) { return (c >> 1) + (c & 1) * 9; }
 __device__ __forceinline__ int stem_key(int c, int t) { return c == 16 ? (t & 7) : (((c & 1) << 2) + ((c >> 2) & 3)); }
 
+#ifndef FLOPE_STEM_WPE
+#define FLOPE_STEM_WPE 3          // workgroups per CU the register-weight stem is compiled for (3: 141 registers; 4: 128 with 6 spilled -- measured equal)
+#endif
 template <typename T, int FMT>
-__global__ __launch_bounds__(256, 3) void stem_pool_r_kernel(const StemPoolP p) {
+__global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const StemPoolP p) {
   typedef typename Elem<T>::frag frag;
   constexpr int PR = 39, PC = 42;
   constexpr int P_BYTES = ((PR * PC * 8 + 15) / 16) * 16;
-  constexpr int CR = 17, CS = 18, NI = 7;                     // conv region 17 x 17; 18 pixel slots per conv row
+  constexpr int CR = 17, CS = 18, NI = 7;                     // conv region 17 x 17; 18 pixel slots per row of the LDS image
+  constexpr int V_BYTES = 8 * CS * 128;                       // vertically pooled rows: [8 pooled rows][18 slots][64 ch]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ps = smem;
-  char* const Cs = smem + P_BYTES;                            // [17][18 slots][64 ch] conv outputs
+  char* const Cs = smem + P_BYTES;                            // the pooled-row image, then [17 rows][64 ch] of conv column 16
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -636,25 +643,36 @@ __global__ __launch_bounds__(256, 3) void stem_pool_r_kernel(const StemPoolP p) 
   const int xb_cor = (2 * (CR - 1) * PC + 2 * (CR - 1)) * 8 + g * 16;
   // conv-output writes: this lane's 4 channels 16 w + 4 g .. of pixel (t, c): 8-byte granule (g & 1) of chunk cg = 2 w + (g >> 1)
   const int cgw = 2 * wave + (g >> 1), subw = (g & 1) * 8;
-  const int cw_row = stem_pi(r16) * 128 + ((cgw ^ stem_key(r16, 0)) << 4) + subw;                       // + t * CS * 128
-  const int cw_col = (r16 * CS + stem_pi(CR - 1)) * 128 + ((cgw ^ stem_key(CR - 1, r16)) << 4) + subw;
-  const int cw_cor = ((CR - 1) * CS + stem_pi(CR - 1)) * 128 + ((cgw ^ stem_key(CR - 1, CR - 1)) << 4) + subw;
-  // pool reads: the nine conv outputs under each of this thread's two items (pooled pixel, 8-channel group)
-  int pro[2][9];
+  const int cw_row = stem_pi(r16) * 128 + ((cgw ^ stem_key(r16, 0)) << 4) + subw;                       // + pooled row * CS * 128
+  const int cw_col = V_BYTES + r16 * 128 + ((cgw ^ (r16 & 7)) << 4) + subw;                             // column 16, conv row r16
+  const int cw_cor = V_BYTES + (CR - 1) * 128 + ((cgw ^ ((CR - 1) & 7)) << 4) + subw;
+  // pool reads of this thread's two items (pooled pixel, 8-channel group): the three vertically pooled columns under it; the last
+  // pooled column takes its third one from the three conv rows of column 16
+  int pro[2][3], pc16[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int i = tid + it * 256, cg = i & 7, pp = i >> 3, pr = pp >> 3, pc = pp & 7;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int qr = 2 * pr + t / 3, qc = 2 * pc + t % 3;
-      pro[it][t] = (qr * CS + stem_pi(qc)) * 128 + ((cg ^ stem_key(qc, qr)) << 4);
+    for (int t = 0; t < 3; ++t) {
+      const int qc = min(2 * pc + t, CR - 2);
+      pro[it][t] = (pr * CS + stem_pi(qc)) * 128 + ((cg ^ stem_key(qc, 0)) << 4);
     }
+    pc16[it] = V_BYTES + (2 * pr) * 128 + (cg << 4);        // + row * 128, chunk cg ^ (row & 7)
   }
 
   int tile = lb;
   if (tile < total) { issue_loads(tile); write_window(); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef FLOPE_STAG_DBG
+  // diagnostic build: cycles of wave 0 in {MFMA phase, barrier, window write + pool, barrier} per workgroup (tools/clock_probe_stem.py)
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_first = t_prev;
+  const unsigned long long rt_first = __builtin_amdgcn_s_memrealtime();
+  int ntile_dbg = 0;
+#define ST_PH(i_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i_] += t_ - t_prev; t_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ST_PH(i_) do {} while (0)
+#endif
 
   for (; tile < total; tile += G) {
     int tx, ty, img;
@@ -671,10 +689,20 @@ __global__ __launch_bounds__(256, 3) void stem_pool_r_kernel(const StemPoolP p) 
     const unsigned long long c16mask = (cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws) ? __ballot(cr0 + r16 >= 0 && cr0 + r16 < p.Hs) : 0ull;
     const bool corner_ok = cr0 + CR - 1 >= 0 && cr0 + CR - 1 < p.Hs && cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws;
     const unsigned long long lanebit = 1ull << lane;
-    auto finish = [&](const f32x4 a_, unsigned long long okm_, int cw_, bool own_) {      // ReLU + pack, one 8-byte write
+    auto relu_pack = [&](const f32x4 a_, unsigned long long okm_) {                        // ReLU + pack (+ zero outside the map)
       u32x2 o_ = u32x2{pk_relu16<T>(pack2<T>(a_[0], a_[1])), pk_relu16<T>(pack2<T>(a_[2], a_[3]))};
       if (!(okm_ & lanebit)) o_ = u32x2{0u, 0u};
-      if (own_) *(u32x2*)(Cs + cw_) = o_;
+      return o_;
+    };
+    // VERTICAL pooling in registers: a lane holds the same conv column in every row tile, so pooled row pr = max(rows 2 pr, 2 pr + 1,
+    // 2 pr + 2) is two packed unsigned maxima per row (ReLU outputs are non-negative: bit order = value order) -- only the 8 pooled rows
+    // go to LDS (8 writes per wave instead of 17, a 18 KB image instead of 39 KB) and the pool phase reads 3 values per item, not 9.
+    u32x2 vm = u32x2{0u, 0u};
+    auto row_done = [&](int t, const f32x4 a_) {              // conv row t (compile-time)
+      const u32x2 o_ = relu_pack(a_, (cr0 + t >= 0 && cr0 + t < p.Hs) ? colmask : 0ull);
+      if (t == 0) { vm = o_; return; }
+      vm = u32x2{pk_max16_nonneg(vm[0], o_[0]), pk_max16_nonneg(vm[1], o_[1])};
+      if ((t & 1) == 0) { *(u32x2*)(Cs + cw_row + (t / 2 - 1) * (CS * 128)) = vm; vm = o_; }
     };
     // The 17 row tiles share window rows: conv row t reads rows 2 t .. 2 t + 6, so every row fragment is read ONCE (39 reads, not
     // 119), two new ones per tile, issued a whole tile ahead of their first MFMA; a tile's epilogue runs behind the NEXT tile's MFMAs
@@ -700,13 +728,18 @@ __global__ __launch_bounds__(256, 3) void stem_pool_r_kernel(const StemPoolP p) 
       f32x4 a_;
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) a_ = Elem<T>::mfma(wf[ky], xr[2 * t + ky], ky == 0 ? b4 : a_);
-      if (t == 0) { finish(a_col, c16mask, cw_col, true); finish(a_cor, corner_ok ? ~0ull : 0ull, cw_cor, r16 == 0); }
-      else finish(a_prev, (cr0 + t - 1 >= 0 && cr0 + t - 1 < p.Hs) ? colmask : 0ull, cw_row + (t - 1) * (CS * 128), true);
+      if (t == 0) {
+        *(u32x2*)(Cs + cw_col) = relu_pack(a_col, c16mask);
+        const u32x2 oc_ = relu_pack(a_cor, corner_ok ? ~0ull : 0ull);
+        if (r16 == 0) *(u32x2*)(Cs + cw_cor) = oc_;
+      } else row_done(t - 1, a_prev);
       a_prev = a_;
       __builtin_amdgcn_sched_barrier(0);
     }
-    finish(a_prev, (cr0 + CR - 1 >= 0 && cr0 + CR - 1 < p.Hs) ? colmask : 0ull, cw_row + (CR - 1) * (CS * 128), true);
+    row_done(CR - 1, a_prev);
+    ST_PH(0);
     __syncthreads();                               // conv outputs complete; Ps is free
+    ST_PH(1);
     if (has_next) write_window();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -715,23 +748,48 @@ __global__ __launch_bounds__(256, 3) void stem_pool_r_kernel(const StemPoolP p) 
       const int pr = pp >> 3, pc = pp & 7;
       const int oy = ty * 8 + pr, ox = tx * 8 + pc;
       if (oy >= p.Hq || ox >= p.Wq) continue;
-      u32x4 o = u32x4{0u, 0u, 0u, 0u};
+      u32x4 o = *(const u32x4*)(Cs + pro[it][0]);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int t = 1; t < 3; ++t) {
         const u32x4 v = *(const u32x4*)(Cs + pro[it][t]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
       }
+      if (pc == 7) {                                 // conv column 16: its three rows, from the side image
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int row = 2 * pr + t;
+          const u32x4 v = *(const u32x4*)(Cs + pc16[it] + t * 128 + (((cg ^ (row & 7)) - cg) << 4));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
+        }
+      }
       char* dst = (char*)p.out + ((((size_t)img * (p.Hq + 2) + oy + 1) * (p.Wq + 2) + ox + 1) * 64 + cg * 8) * 2;
       *(u32x4*)dst = o;
     }
+    ST_PH(2);
     __syncthreads();                               // pool done with Cs, window written: next tile
+    ST_PH(3);
+#ifdef FLOPE_STAG_DBG
+    ++ntile_dbg;
+#endif
   }
+#ifdef FLOPE_STAG_DBG
+  if (p.dbg && tid == 0) {
+    unsigned long long* d_ = p.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 4; ++i) d_[i] = ph[i];
+    d_[4] = __builtin_amdgcn_s_memrealtime() - rt_first;      // 100 MHz ticks over the same span as d_[6]: the shader clock
+    d_[5] = (unsigned long long)ntile_dbg; d_[6] = __builtin_amdgcn_s_memtime() - t_first; d_[7] = 0;
+  }
+#endif
+#undef ST_PH
 }
 
 // (r02 also built a register-pool form -- 7 x 7 pooled pixels per workgroup, pooling by v_pk_max across accumulator tiles and DPP
 // row shifts, no conv-output buffer in LDS, three workgroups per CU.  Bit-identical and slower: 197 vs 150 us at 224 x 224, 983 vs
 // 697 us at 512 x 512 (+30 % MFMAs for the conv rows computed twice).  Removed in r04; numbers in DESIGN.md 4.2.)
+
+extern "C" int flope_stem_pool_r_blocks_per_cu() { return FLOPE_STEM_WPE; }
 
 extern "C" size_t flope_stem_pool_lds() { return 7 * 64 * 64 + ((39 * 42 * 8 + 15) / 16) * 16; }
 
@@ -770,7 +828,7 @@ extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H
     const int total = B * p.tiles_y * p.tiles_x;
     const dim3 pgrid(persist_blocks < total ? persist_blocks : total);
     if (w2) {
-      const size_t rlds = ((39 * 42 * 8 + 15) / 16) * 16 + 17 * 18 * 128;
+      const size_t rlds = ((39 * 42 * 8 + 15) / 16) * 16 + 8 * 18 * 128 + 17 * 128;
 #define RL(T_, F_) hipLaunchKernelGGL((stem_pool_r_kernel<T_, F_>), pgrid, block, rlds, (hipStream_t)stream, p)
       if (dtype == 0) { if (in_format == 0) RL(bf16_t, 0); else if (in_format == 1) RL(bf16_t, 1); else if (in_format == 2) RL(bf16_t, 2); else RL(bf16_t, 3); }
       else            { if (in_format == 0) RL(f16_t, 0); else if (in_format == 1) RL(f16_t, 1); else if (in_format == 2) RL(f16_t, 2); else RL(f16_t, 3); }

@@ -19,6 +19,8 @@ x = torch.rand(B, S, S, 3).to(torch.float16).cuda()
 R = torch.empty(B, 9, device="cuda")
 e = PoseEngine(S, S, B, "f16")
 e.set_option("streams", streams)
+stem_r = int(os.environ.get("STEM_R", 1))
+e.set_option("stem_r", stem_r)
 e.load_state_dict(synthetic_state_dict(0))
 e.set_option("dbg", 64)
 t0 = time.time()
@@ -26,18 +28,22 @@ while time.time() - t0 < 2.0:
     for _ in range(20):
         e.forward_into(x, 2, None, R)
     torch.cuda.synchronize()
-buf = np.zeros(1024 * 8, dtype=np.uint64)
+buf = np.zeros(1024 * 8, dtype=np.uint64)       # up to 4 workgroups per CU
 rc = e.lib.flope_debug_read_ws(e.handle, buf.ctypes.data_as(C.c_void_p), C.c_size_t(30 * 1048576), C.c_size_t(buf.nbytes))
 assert rc == 0
 r = buf.reshape(-1, 8).astype(np.int64)
 r = r[(r[:, 5] > 0) & (r[:, 6] > 0) & (r[:, 6] < 10**9)]
 tiles = r[:, 5]
-names = ["loads issue + acc init + MFMA phase", "barrier 1", "window write + ReLU -> Cs", "barrier 2", "pool + store"]
+names = (["loads issue + MFMA phase (+ ReLU, vertical max, 8 LDS writes)", "barrier 1", "window write + pool + store", "barrier 2"] if stem_r else
+         ["loads issue + acc init + MFMA phase", "barrier 1", "window write + ReLU -> Cs", "barrier 2", "pool + store"])
+if stem_r:
+    print(f"shader clock over the workgroups' lifetime: {np.median(r[:, 6] / np.maximum(r[:, 4], 1)) * 0.1:.3f} GHz; lifetime {np.median(r[:, 4]) / 100:.1f} us")
 print(f"B={B} S={S} streams={streams}: {len(r)} workgroups, {int(tiles.sum())} tiles; cycles per tile and workgroup (median over workgroups)")
 tot = 0
 for i, n in enumerate(names):
     v = np.median(r[:, i] / tiles)
     tot += v
     print(f"  {n:40s} {v:8.0f}")
-print(f"  {'(of phase 0: tile decode + loads issue)':40s} {np.median(r[:, 7] / tiles):8.0f}")
+if not stem_r:
+    print(f"  {'(of phase 0: tile decode + loads issue)':40s} {np.median(r[:, 7] / tiles):8.0f}")
 print(f"  {'sum':40s} {tot:8.0f}   (MFMA floor per tile and wave: 140 MFMAs x 16 = 2240)")
