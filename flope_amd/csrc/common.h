@@ -68,6 +68,13 @@ __device__ __forceinline__ unsigned pk_max16_nonneg(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
 }
 
+// maximum of packed pairs as SIGNED 16-bit integers: equals the float maximum of the two f16 / bf16 values whenever that maximum is
+// non-negative (non-negative patterns order like integers and sit above every negative one); when both are negative it returns a
+// negative value -- which a following ReLU turns into the same 0 the float maximum would give.  (stem: vertical pool before ReLU)
+__device__ __forceinline__ unsigned pk_max16_signed(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b)));
+}
+
 // 16-bit store of an epilogue pair: optional ReLU, and for float16 saturation at +-65504 -- a residual stream that
 // outgrows the float16 range would otherwise become inf here, NaN one layer later and a garbage rotation with no error
 // (bfloat16 has float32's range and needs nothing).  One v_pk_min_f16 (+ v_pk_max_f16 without ReLU) per two channels.

@@ -543,11 +543,23 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
   const int G = gridDim.x, total = p.B * p.tiles_y * p.tiles_x;
   const int lb = xcd_remap(blockIdx.x, G);
 
-  // this wave's weights: seven fragments, straight from global memory in fragment order (one contiguous KiB per wave-load)
+  // this wave's weights: seven fragments + its bias, in fragment order in global memory (one contiguous KiB per wave-load).  They
+  // take a detour through LDS (each lane parks its own 8 x 16 bytes and reads them back: no barrier in between): registers that a
+  // GLOBAL load wrote in front of the loop make hipcc's wait-count pass put `s_waitcnt vmcnt(0)` in front of the loop's first MFMA --
+  // i.e. behind the next window's fourteen loads, whose flight time the MFMA phase is there to hide.
   frag wf[7];
+  f32x4 b4;
+  {
+    char* const wl = smem + wave * 8192 + lane * 16;
 #pragma unroll
-  for (int ky = 0; ky < 7; ++ky) wf[ky] = *(const frag*)((const char*)p.w2 + ((size_t)(wave * 7 + ky) * 64 + lane) * 16);
-  const f32x4 b4 = *(const f32x4*)(p.bias + wave * 16 + g * 4);
+    for (int ky = 0; ky < 7; ++ky) *(frag*)(wl + ky * 1024) = *(const frag*)((const char*)p.w2 + ((size_t)(wave * 7 + ky) * 64 + lane) * 16);
+    *(f32x4*)(wl + 7 * 1024) = *(const f32x4*)(p.bias + wave * 16 + g * 4);
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) wf[ky] = *(const frag*)(wl + ky * 1024);
+    b4 = *(const f32x4*)(wl + 7 * 1024);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                               // the staging area is the window / pooled-row image from here on
+  }
 
   // ---- staging geometry of this thread (tile independent): window column c, rows r0 + 6k   (as stem_pool_persist_kernel)
   const bool stager = tid < 6 * PC;
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
   const int cw_cor = V_BYTES + (CR - 1) * 128 + ((cgw ^ ((CR - 1) & 7)) << 4) + subw;
   // pool reads of this thread's two items (pooled pixel, 8-channel group): the three vertically pooled columns under it; the last
   // pooled column takes its third one from the three conv rows of column 16
-  int pro[2][3], pc16[2];
+  int pro[2][3], pc16[2][3];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int i = tid + it * 256, cg = i & 7, pp = i >> 3, pr = pp >> 3, pc = pp & 7;
@@ -657,7 +669,8 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
       const int qc = min(2 * pc + t, CR - 2);
       pro[it][t] = (pr * CS + stem_pi(qc)) * 128 + ((cg ^ stem_key(qc, 0)) << 4);
     }
-    pc16[it] = V_BYTES + (2 * pr) * 128 + (cg << 4);        // + row * 128, chunk cg ^ (row & 7)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) pc16[it][t] = V_BYTES + (2 * pr + t) * 128 + ((cg ^ ((2 * pr + t) & 7)) << 4);
   }
 
   int tile = lb;
@@ -681,62 +694,77 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
     const bool has_next = tile + G < total;
     if (has_next) issue_loads(tile + G);           // in flight during the MFMA phase
     asm volatile("" ::: "memory");
-    // Conv positions outside the feature map (the -1 row / column of top / left tiles, the tail of a ragged last tile) must be 0:
-    // neutral for a max over ReLU outputs.  Branch-free -- a branch per pixel tile cuts the stream into basic blocks and the
-    // compiler then issues every fragment read right in front of its MFMA (r05 first version: 64+ cycles of LDS latency exposed per
-    // tile): the row test is wave-uniform per tile, the column test per lane and tile-independent -> one 64-bit lane mask per tile.
-    const unsigned long long colmask = __ballot(cc0 + r16 >= 0 && cc0 + r16 < p.Ws);
-    const unsigned long long c16mask = (cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws) ? __ballot(cr0 + r16 >= 0 && cr0 + r16 < p.Hs) : 0ull;
-    const bool corner_ok = cr0 + CR - 1 >= 0 && cr0 + CR - 1 < p.Hs && cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws;
-    const unsigned long long lanebit = 1ull << lane;
-    auto relu_pack = [&](const f32x4 a_, unsigned long long okm_) {                        // ReLU + pack (+ zero outside the map)
-      u32x2 o_ = u32x2{pk_relu16<T>(pack2<T>(a_[0], a_[1])), pk_relu16<T>(pack2<T>(a_[2], a_[3]))};
-      if (!(okm_ & lanebit)) o_ = u32x2{0u, 0u};
-      return o_;
+    // Per row tile the wave's vector instructions, not its MFMAs, are what the SIMD runs out of (r05 counters: ~1000 instructions per
+    // tile and wave around 133 MFMAs; three or four workgroups per CU, priorities, a one-barrier software pipeline: all the same
+    // time), so the epilogue is cut to the bone:
+    //   * ReLU and the float16 clamp commute with the maximum, and a SIGNED 16-bit integer maximum orders IEEE bit patterns correctly
+    //     whenever the result is non-negative (and any negative result is a 0 after ReLU): the vertical pool runs on the raw packed
+    //     conversions -- 2 cvt_pk + 2 v_pk_max_i16 per conv row -- and ReLU + clamp are applied once per POOLED row (same bits);
+    //   * conv positions outside the feature map (the -1 row / column of top / left tiles, the tail of a ragged last tile) must
+    //     contribute 0.  Only tiles on the border have any: the tile body exists twice, and the interior version carries no masks
+    //     at all; the border version ANDs a per-lane column mask, selected per row by one scalar bit.  (Branch-free inside a body: a
+    //     branch per pixel tile cuts the stream into basic blocks and the compiler then issues every fragment read right in front
+    //     of its MFMA.)
+    const bool edge = cr0 < 0 || cc0 < 0 || cr0 + CR > p.Hs || cc0 + CR > p.Ws;
+    auto body = [&](auto edge_c) {
+      constexpr bool EDGE = decltype(edge_c)::value;
+      unsigned colm = 0xffffffffu, c16m = 0xffffffffu, corm = 0xffffffffu, rowbits = 0x1ffffu;
+      if constexpr (EDGE) {
+        colm = (cc0 + r16 >= 0 && cc0 + r16 < p.Ws) ? 0xffffffffu : 0u;
+        c16m = (cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws && cr0 + r16 >= 0 && cr0 + r16 < p.Hs) ? 0xffffffffu : 0u;
+        corm = (cr0 + CR - 1 >= 0 && cr0 + CR - 1 < p.Hs && cc0 + CR - 1 >= 0 && cc0 + CR - 1 < p.Ws) ? 0xffffffffu : 0u;
+        const int lo_ = max(0, -cr0), hi_ = min(CR, p.Hs - cr0);                  // valid conv rows of this tile: [lo_, hi_)
+        rowbits = hi_ > lo_ ? ((1u << hi_) - 1u) & ~((1u << lo_) - 1u) : 0u;
+      }
+      auto raw_pack = [&](const f32x4 a_) { return u32x2{pack2<T>(a_[0], a_[1]), pack2<T>(a_[2], a_[3])}; };
+      auto relu_clamp = [&](const u32x2 v_) { return u32x2{pk_relu16<T>(v_[0]), pk_relu16<T>(v_[1])}; };
+      u32x2 vm = u32x2{0u, 0u};
+      auto row_done = [&](int t, const f32x4 a_) {            // conv row t (compile-time)
+        u32x2 o_ = raw_pack(a_);
+        if constexpr (EDGE) {
+          const unsigned m_ = ((rowbits >> t) & 1u) ? colm : 0u;
+          o_ = u32x2{o_[0] & m_, o_[1] & m_};
+        }
+        if (t == 0) { vm = o_; return; }
+        vm = u32x2{pk_max16_signed(vm[0], o_[0]), pk_max16_signed(vm[1], o_[1])};
+        if ((t & 1) == 0) { *(u32x2*)(Cs + cw_row + (t / 2 - 1) * (CS * 128)) = relu_clamp(vm); vm = o_; }
+      };
+      // The 17 row tiles share window rows: conv row t reads rows 2 t .. 2 t + 6, so every row fragment is read ONCE (39 reads, not
+      // 119), two new ones per tile, issued a whole tile ahead of their first MFMA; a tile's epilogue runs behind the NEXT tile's
+      // MFMAs (its accumulators have long landed).  The column tile and the corner (7 reads each) go first.
+      frag xr[PR];
+#pragma unroll
+      for (int r = 0; r < 7; ++r) xr[r] = *(const frag*)(Ps + xb_row + r * (PC * 8));
+      f32x4 a_col, a_cor, a_prev;
+      {
+        frag xc[7], xk[7];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) { xc[ky] = *(const frag*)(Ps + xb_col + ky * (PC * 8)); xk[ky] = *(const frag*)(Ps + xb_cor + ky * (PC * 8)); }
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) a_col = Elem<T>::mfma(wf[ky], xc[ky], ky == 0 ? b4 : a_col);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) a_cor = Elem<T>::mfma(wf[ky], xk[ky], ky == 0 ? b4 : a_cor);
+      }
+#pragma unroll
+      for (int t = 0; t < CR; ++t) {
+        if (2 * t + 7 < PR) xr[2 * t + 7] = *(const frag*)(Ps + xb_row + (2 * t + 7) * (PC * 8));
+        if (2 * t + 8 < PR) xr[2 * t + 8] = *(const frag*)(Ps + xb_row + (2 * t + 8) * (PC * 8));
+        __builtin_amdgcn_sched_barrier(0);           // the reads stay HERE, a tile ahead of their first use (left alone, the scheduler sinks them in front of it)
+        f32x4 a_;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) a_ = Elem<T>::mfma(wf[ky], xr[2 * t + ky], ky == 0 ? b4 : a_);
+        if (t == 0) {
+          u32x2 oc_ = relu_clamp(raw_pack(a_col)), ok_ = relu_clamp(raw_pack(a_cor));
+          if constexpr (EDGE) { oc_ = u32x2{oc_[0] & c16m, oc_[1] & c16m}; ok_ = u32x2{ok_[0] & corm, ok_[1] & corm}; }
+          *(u32x2*)(Cs + cw_col) = oc_;
+          if (r16 == 0) *(u32x2*)(Cs + cw_cor) = ok_;
+        } else row_done(t - 1, a_prev);
+        a_prev = a_;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      row_done(CR - 1, a_prev);
     };
-    // VERTICAL pooling in registers: a lane holds the same conv column in every row tile, so pooled row pr = max(rows 2 pr, 2 pr + 1,
-    // 2 pr + 2) is two packed unsigned maxima per row (ReLU outputs are non-negative: bit order = value order) -- only the 8 pooled rows
-    // go to LDS (8 writes per wave instead of 17, a 18 KB image instead of 39 KB) and the pool phase reads 3 values per item, not 9.
-    u32x2 vm = u32x2{0u, 0u};
-    auto row_done = [&](int t, const f32x4 a_) {              // conv row t (compile-time)
-      const u32x2 o_ = relu_pack(a_, (cr0 + t >= 0 && cr0 + t < p.Hs) ? colmask : 0ull);
-      if (t == 0) { vm = o_; return; }
-      vm = u32x2{pk_max16_nonneg(vm[0], o_[0]), pk_max16_nonneg(vm[1], o_[1])};
-      if ((t & 1) == 0) { *(u32x2*)(Cs + cw_row + (t / 2 - 1) * (CS * 128)) = vm; vm = o_; }
-    };
-    // The 17 row tiles share window rows: conv row t reads rows 2 t .. 2 t + 6, so every row fragment is read ONCE (39 reads, not
-    // 119), two new ones per tile, issued a whole tile ahead of their first MFMA; a tile's epilogue runs behind the NEXT tile's MFMAs
-    // (its accumulators have long landed).  The column tile and the corner (7 reads each) go first.
-    frag xr[PR];
-#pragma unroll
-    for (int r = 0; r < 7; ++r) xr[r] = *(const frag*)(Ps + xb_row + r * (PC * 8));
-    f32x4 a_col, a_cor, a_prev;
-    {
-      frag xc[7], xk[7];
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) { xc[ky] = *(const frag*)(Ps + xb_col + ky * (PC * 8)); xk[ky] = *(const frag*)(Ps + xb_cor + ky * (PC * 8)); }
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) a_col = Elem<T>::mfma(wf[ky], xc[ky], ky == 0 ? b4 : a_col);
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) a_cor = Elem<T>::mfma(wf[ky], xk[ky], ky == 0 ? b4 : a_cor);
-    }
-#pragma unroll
-    for (int t = 0; t < CR; ++t) {
-      if (2 * t + 7 < PR) xr[2 * t + 7] = *(const frag*)(Ps + xb_row + (2 * t + 7) * (PC * 8));
-      if (2 * t + 8 < PR) xr[2 * t + 8] = *(const frag*)(Ps + xb_row + (2 * t + 8) * (PC * 8));
-      __builtin_amdgcn_sched_barrier(0);             // the reads stay HERE, a tile ahead of their first use (left alone, the scheduler sinks them in front of it)
-      f32x4 a_;
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) a_ = Elem<T>::mfma(wf[ky], xr[2 * t + ky], ky == 0 ? b4 : a_);
-      if (t == 0) {
-        *(u32x2*)(Cs + cw_col) = relu_pack(a_col, c16mask);
-        const u32x2 oc_ = relu_pack(a_cor, corner_ok ? ~0ull : 0ull);
-        if (r16 == 0) *(u32x2*)(Cs + cw_cor) = oc_;
-      } else row_done(t - 1, a_prev);
-      a_prev = a_;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    row_done(CR - 1, a_prev);
+    if (edge) body(std::true_type()); else body(std::false_type());
     ST_PH(0);
     __syncthreads();                               // conv outputs complete; Ps is free
     ST_PH(1);
@@ -758,8 +786,7 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
       if (pc == 7) {                                 // conv column 16: its three rows, from the side image
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          const int row = 2 * pr + t;
-          const u32x4 v = *(const u32x4*)(Cs + pc16[it] + t * 128 + (((cg ^ (row & 7)) - cg) << 4));
+          const u32x4 v = *(const u32x4*)(Cs + pc16[it][t]);
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = pk_max16_nonneg(o[k], v[k]);
         }
