@@ -47,7 +47,7 @@ extern "C" int flope_stem_pool_r_blocks_per_cu();
 extern "C" void flope_stem_pool_set_dbg(void* ptr);
 #endif
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq, int Wq,
-                                      const void* w, const void* w2, const float* bias, void* out, int dtype, int persist_blocks, void* stream);
+                                      const void* w, const void* w2, int* queues, const float* bias, void* out, int dtype, int persist_blocks, void* stream);
 
 using namespace flope_host;
 
@@ -97,6 +97,7 @@ struct flope_engine {
   int sHip = 0, sWip = 0, Hs = 0, Ws = 0, stem_tiles = 0, stem_rows = 0;
   size_t stem_lds = 0;
   void* stem_in = nullptr; size_t stem_in_bytes = 0;
+  int* stem_q = nullptr;               // tile queues of the register-weight stem: 1024 ints per batch slice (heads 256 bytes apart; zero between launches)
   void* stem_w = nullptr; void* stem_w2 = nullptr; float* stem_w_naive = nullptr; float* stem_bias = nullptr;   // stem_w2: per-wave fragment order (stem_pool_r_kernel)
   std::vector<Buf> bufs;             // 0 stem_out, 1 pool, then per block: mid, [ds], out
   std::vector<Conv> convs;
@@ -497,6 +498,8 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
   if (dtype != FLOPE_DT_F32) {          // split-K partials: tiles * ksplit <= num_cus, 256 x 128 fp32 per tile share
     e->split_ws_bytes = (size_t)e->num_cus * 256 * 128 * sizeof(float);
     CREATE_TRY(hipMalloc((void**)&e->split_ws, e->split_ws_bytes));
+    CREATE_TRY(hipMalloc((void**)&e->stem_q, 4 * 1024 * sizeof(int)));
+    CREATE_TRY(hipMemset(e->stem_q, 0, 4 * 1024 * sizeof(int)));
   }
   for (int i = 0; i < 4; ++i) {
     CREATE_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
@@ -519,7 +522,7 @@ extern "C" int flope_destroy(flope_handle e) {
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
   for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.bias_fused) hipFree(c.bias_fused); }
-  void* singles[] = {e->stem_in, e->stem_w, e->stem_w2, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
+  void* singles[] = {e->stem_in, e->stem_q, e->stem_w, e->stem_w2, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) { if (e->side[i]) hipStreamDestroy(e->side[i]); if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]); }
@@ -676,8 +679,9 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
     // r05: the register-weight form (weights in VGPRs, 51 KB of LDS: three workgroups per CU) where the option asks for it; else the
     // r02 forms -- persistent where that measured faster (same-run A/B at B = 256: 224 x 224 crops +2.7 % on the step; 512 x 512
     // crops -7 % on the kernel.  stem_persist: 1 = auto, 2 = always, 0 = never)
-    const bool stem_r = e->opt_stem_r && e->stem_w2;
+    const bool stem_r = e->opt_stem_r && e->stem_w2 && e->stem_q;
     K_TRY(e, "stem+maxpool", flope_stem_pool_launch(x, in_format, batch, e->H, e->W, e->Hs, e->Ws, bp.h, bp.w, e->stem_w, stem_r ? e->stem_w2 : nullptr,
+                                                   stem_r ? e->stem_q + 1024 * (e->cur_slices > 1 ? e->mark_slice : 0) : nullptr,
                                                    e->stem_bias, bp.ptr, dt,
                                                    stem_r ? flope_stem_pool_r_blocks_per_cu() * e->num_cus
                                                           : (e->opt_stem_persist == 2 || (e->opt_stem_persist == 1 && bp.h * bp.w <= 64 * 64)) ? 2 * e->num_cus : 0,

@@ -24,6 +24,8 @@ struct StemPoolP {
   void* out;           // padded NHWC [B][Hq+2][Wq+2][64]
   const void* w;       // packed [7 ky][64 rows][32 k] LDS image (host_pack.h pack_stem)
   const void* w2;      // the same weights in per-wave A-fragment order (host_pack.h pack_stem_frag): stem_pool_r_kernel
+  int* q;              // stem_pool_r_kernel: eight tile-queue heads + a count of finished workgroups, 256 bytes apart (one word saturates
+                       // at ~88 pulls / us, and heads on ONE line behaved like one word: 10 us per pull); zero between launches
   const float* bias;   // [64]
   int in_format;       // FLOPE_IN_*
   int B, H, W;         // crop size
@@ -534,6 +536,9 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
   constexpr int CR = 17, CS = 18, NI = 7;                     // conv region 17 x 17; 18 pixel slots per row of the LDS image
   constexpr int V_BYTES = 8 * CS * 128;                       // vertically pooled rows: [8 pooled rows][18 slots][64 ch]
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FLOPE_STAG_DBG
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   char* const Ps = smem;
   char* const Cs = smem + P_BYTES;                            // the pooled-row image, then [17 rows][64 ch] of conv column 16
 
@@ -541,7 +546,34 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r16 = lane & 15;
   const int G = gridDim.x, total = p.B * p.tiles_y * p.tiles_x;
+  // Static walk first, work queues for the tail (r05 stamps: with a purely static partition the workgroups of a launch finished anywhere
+  // between 61 and 98 us -- co-resident waves are not served equally -- and the CUs idled behind their fastest workgroups; with every
+  // tile pulled from a queue the finish times met within 10 us but each pull cost ~1.8 k cycles of a tile).  The first nstat rounds of
+  // the grid (3/4 of the tiles) are walked as before, tile = lb + j G; the rest sits in eight queues, one per XCD: queue x holds the
+  // contiguous range [S + x R / 8, S + (x + 1) R / 8) (neighbouring tiles share window rows: same L2), a workgroup pulls from the queue
+  // of the XCD it runs on (HW_REG_XCC_ID) and, once that is empty, from the others in turn.  p.q = eight heads + a count of finished
+  // workgroups, 256 bytes apart; the last workgroup out zeroes them for the next launch.  A pull is issued at the start of a tile and
+  // read behind its first barrier.
   const int lb = xcd_remap(blockIdx.x, G);
+  const int nstat = (int)((long long)total * 3 / 4 / G);            // static rounds
+  const int S0 = nstat * G, RT = total - S0;                          // queue region [S0, total)
+  const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+  int* const qn = (int*)(smem + P_BYTES + V_BYTES + CR * 128);      // one word of LDS: the next tile index, from thread 0 to everybody
+  const int qlo = S0 + (int)((long long)xcc * RT / 8), qhi = S0 + (int)((long long)(xcc + 1) * RT / 8);
+  auto pull_issue = [&]() -> int {                                  // (thread 0) the atomic only: its value is looked at a phase later
+    return __hip_atomic_fetch_add(p.q + xcc * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto pull_resolve = [&](int raw) -> int {                         // (thread 0) own queue, or -- once it is empty -- the others in turn
+    if (qlo + raw < qhi) return qlo + raw;
+    for (int k = 1; k < 8; ++k) {
+      const int x = (xcc + k) & 7;
+      const int lo = S0 + (int)((long long)x * RT / 8), hi = S0 + (int)((long long)(x + 1) * RT / 8);
+      if (lo >= hi) continue;
+      const int t = lo + __hip_atomic_fetch_add(p.q + x * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t < hi) return t;
+    }
+    return total;
+  };
 
   // this wave's weights: seven fragments + its bias, in fragment order in global memory (one contiguous KiB per wave-load).  They
   // take a detour through LDS (each lane parks its own 8 x 16 bytes and reads them back: no barrier in between): registers that a
@@ -673,9 +705,17 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
     for (int t = 0; t < 3; ++t) pc16[it][t] = V_BYTES + (2 * pr + t) * 128 + ((cg ^ ((2 * pr + t) & 7)) << 4);
   }
 
-  int tile = lb;
+  if (tid == 0) {
+    int t0_ = lb, t1_ = lb + G;                                     // static rounds 0 and 1, or pulls where there are none
+    if (nstat < 1) { const int r0_ = pull_issue(), r1_ = pull_issue(); t0_ = pull_resolve(r0_); t1_ = pull_resolve(r1_); }
+    else if (nstat < 2) t1_ = pull_resolve(pull_issue());
+    qn[0] = t0_; qn[1] = t1_;
+  }
+  __syncthreads();
+  int tile = qn[0], tile_next = qn[1];
+  int jt = 0;                                                       // tiles this workgroup has started
   if (tile < total) { issue_loads(tile); write_window(); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 #ifdef FLOPE_STAG_DBG
   // diagnostic build: cycles of wave 0 in {MFMA phase, barrier, window write + pool, barrier} per workgroup (tools/clock_probe_stem.py)
@@ -687,12 +727,15 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
 #define ST_PH(i_) do {} while (0)
 #endif
 
-  for (; tile < total; tile += G) {
+  for (; tile < total; tile = tile_next, tile_next = qn[0], ++jt) {
     int tx, ty, img;
     tile_origin(tile, tx, ty, img);
     const int cr0 = 2 * (ty * 8) - 1, cc0 = 2 * (tx * 8) - 1;
-    const bool has_next = tile + G < total;
-    if (has_next) issue_loads(tile + G);           // in flight during the MFMA phase
+    const bool has_next = tile_next < total;
+    if (has_next) issue_loads(tile_next);          // in flight during the MFMA phase
+    const bool dyn2 = jt + 2 >= nstat;             // the tile after that: still a static round, or a pull (its round trip behind the MFMA phase)
+    int praw = 0;
+    if (tid == 0 && has_next && dyn2) praw = pull_issue();
     asm volatile("" ::: "memory");
     // Per row tile the wave's vector instructions, not its MFMAs, are what the SIMD runs out of (r05 counters: ~1000 instructions per
     // tile and wave around 133 MFMAs; three or four workgroups per CU, priorities, a one-barrier software pipeline: all the same
@@ -766,7 +809,8 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
     };
     if (edge) body(std::true_type()); else body(std::false_type());
     ST_PH(0);
-    __syncthreads();                               // conv outputs complete; Ps is free
+    if (tid == 0) qn[0] = !has_next ? total : (dyn2 ? pull_resolve(praw) : lb + (jt + 2) * G);
+    __syncthreads();                               // conv outputs complete; Ps is free; the next-but-one tile index is published
     ST_PH(1);
     if (has_next) write_window();
 #pragma unroll
@@ -807,9 +851,17 @@ __global__ __launch_bounds__(256, FLOPE_STEM_WPE) void stem_pool_r_kernel(const 
     for (int i = 0; i < 4; ++i) d_[i] = ph[i];
     d_[4] = __builtin_amdgcn_s_memrealtime() - rt_first;      // 100 MHz ticks over the same span as d_[6]: the shader clock
     d_[5] = (unsigned long long)ntile_dbg; d_[6] = __builtin_amdgcn_s_memtime() - t_first; d_[7] = 0;
+    unsigned long long* a_ = p.dbg + 16384 + (size_t)blockIdx.x * 4;      // absolute 100 MHz times: kernel entry, loop start, exit; XCC id
+    a_[0] = rt_entry; a_[1] = rt_first; a_[2] = __builtin_amdgcn_s_memrealtime(); a_[3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
   }
 #endif
 #undef ST_PH
+  if (tid == 0) {                                  // the last workgroup out resets the queues for the next launch on this slice
+    if (__hip_atomic_fetch_add(p.q + 8 * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) __hip_atomic_store(p.q + x * 64, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // (r02 also built a register-pool form -- 7 x 7 pooled pixels per workgroup, pooling by v_pk_max across accumulator tiles and DPP
@@ -832,20 +884,21 @@ extern "C" int flope_stem_pool_init() {
 }
 
 // persist_blocks > 0: a persistent kernel on that many workgroups; 0: one workgroup per tile.
-// w2 != nullptr (and persist_blocks > 0): the register-weight form (stem_pool_r_kernel; persist_blocks should be 3 per CU).
+// w2 and queues != nullptr (and persist_blocks > 0): the register-weight form (stem_pool_r_kernel; persist_blocks = 3 per CU; queues =
+// 9 x 64 zeroed ints -- heads 256 bytes apart -- that no other launch in flight uses).
 #ifdef FLOPE_STAG_DBG
 static unsigned long long* g_stem_dbg = nullptr;
 extern "C" void flope_stem_pool_set_dbg(void* ptr) { g_stem_dbg = (unsigned long long*)ptr; }
 #endif
 
 extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H, int W, int Hs, int Ws_, int Hq,
-                                      int Wq, const void* w, const void* w2, const float* bias, void* out, int dtype, int persist_blocks,
+                                      int Wq, const void* w, const void* w2, int* queues, const float* bias, void* out, int dtype, int persist_blocks,
                                       void* stream) {
   StemPoolP p;
 #ifdef FLOPE_STAG_DBG
   p.dbg = g_stem_dbg;
 #endif
-  p.x = x; p.out = out; p.w = w; p.w2 = w2; p.bias = bias; p.in_format = in_format;
+  p.x = x; p.out = out; p.w = w; p.w2 = w2; p.q = queues; p.bias = bias; p.in_format = in_format;
   p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws_; p.Hq = Hq; p.Wq = Wq;
   p.tiles_y = (Hq + 7) / 8; p.tiles_x = (Wq + 7) / 8;
   flope_host::fastdiv_magic((unsigned)p.tiles_x, &p.mg_tx, &p.sh_tx);
@@ -854,8 +907,8 @@ extern "C" int flope_stem_pool_launch(const void* x, int in_format, int B, int H
   if (persist_blocks > 0) {
     const int total = B * p.tiles_y * p.tiles_x;
     const dim3 pgrid(persist_blocks < total ? persist_blocks : total);
-    if (w2) {
-      const size_t rlds = ((39 * 42 * 8 + 15) / 16) * 16 + 8 * 18 * 128 + 17 * 128;
+    if (w2 && queues) {
+      const size_t rlds = ((39 * 42 * 8 + 15) / 16) * 16 + 8 * 18 * 128 + 17 * 128 + 16;
 #define RL(T_, F_) hipLaunchKernelGGL((stem_pool_r_kernel<T_, F_>), pgrid, block, rlds, (hipStream_t)stream, p)
       if (dtype == 0) { if (in_format == 0) RL(bf16_t, 0); else if (in_format == 1) RL(bf16_t, 1); else if (in_format == 2) RL(bf16_t, 2); else RL(bf16_t, 3); }
       else            { if (in_format == 0) RL(f16_t, 0); else if (in_format == 1) RL(f16_t, 1); else if (in_format == 2) RL(f16_t, 2); else RL(f16_t, 3); }
