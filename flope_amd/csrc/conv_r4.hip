@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
   // fabric twice: 1.31 - 1.33 x the algorithmic bytes, r03 counters), and the last, partly filled round is spread over all eight
   // XCDs (xcd_remap's order left it on four of them: -1.3 % on the two-slice step).  Time: unchanged within noise (the launch is
   // bound by the bytes it has to move), fabric traffic: down.
+#ifdef FLOPE_STAG_DBG
+  const unsigned long long rt_entry_ = __builtin_amdgcn_s_memrealtime();      // r05: finish-time spread of the workgroups of a launch
+#endif
   const int G = gridDim.x;
   int tile = blockIdx.x, tstep = G, tend = p.total_tiles;
   if ((G & 7) == 0) {
@@ -317,6 +320,12 @@ __global__ __launch_bounds__(256, 1) void conv_r4_kernel(const ConvP p) {
     R0 = nR0; m0 = nm0; patch_src = n_patch_src;
   }
   R4_WAIT_VM0();
+#ifdef FLOPE_STAG_DBG
+  if ((p.dbg & 64) && p.split_ws && wave == 0 && lane == 0) {
+    unsigned long long* d_ = (unsigned long long*)((char*)p.split_ws + 65536) + (size_t)blockIdx.x * 4;
+    d_[0] = rt_entry_; d_[1] = __builtin_amdgcn_s_memrealtime(); d_[2] = (unsigned long long)st_it; d_[3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+  }
+#endif
 #undef R4_STAMP
 #undef R4_SUB
 #undef R4_GRP
