@@ -3,7 +3,7 @@
 # FETCH_SIZE calibration, and the side benches.  Output under gpurun_out/$1 (default r02).
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -32,7 +32,8 @@ python tools/make_traffic_json.py $OUT > $OUT/traffic.json
 cp $OUT/traffic.json profiles/$(echo $TAG | sed -E "s/^(r[0-9]+).*/\\1/")_traffic.json      # bench.py reads the committed file (newest round first): same sources, same digest
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 16
 echo "bench done"
-python tools/bench_e2e.py yolo 4 16 31 > $OUT/e2e.txt 2>&1
+YOLO_DTYPE=f32 python tools/bench_e2e.py yolo 4 16 31 > $OUT/e2e.txt 2>&1
+YOLO_DTYPE=f16 python tools/bench_e2e.py yolo > $OUT/e2e_f16_detector.txt 2>&1
 python tools/bench_yolo.py > $OUT/yolo_bench.json 2> $OUT/yolo_bench.err
 python tools/bench_yolo.py --batch 0 >> $OUT/yolo_bench.json 2>> $OUT/yolo_bench.err
 python tools/bench_yolo.py --per-launch 2> /dev/null > $OUT/yolo_per_launch.txt

@@ -24,7 +24,9 @@ def main():
     torch.save({**synthetic_yolo_state_dict(0), "imgsz": torch.tensor(1280)}, yolo_f)
     rgb = synthetic_frame(0)
     depth = (400 + np.random.default_rng(0).normal(0, 4, rgb.shape[:2])).astype(np.uint16)
-    pred = F.FastPosePredictor("cuda", yolo_f, ckpt, intr)
+    ydt = os.environ.get("YOLO_DTYPE", "f32")
+    pred = F.FastPosePredictor("cuda", yolo_f, ckpt, intr, yolo_dtype=ydt)
+    print(f"detector dtype: {ydt}")
     dev = torch.device("cuda")
     for _ in range(5):
         pred.get_flower_poses(rgb, depth)
@@ -48,10 +50,10 @@ def main():
         fd = phase("frame H2D (pageable numpy -> device buffer)", lambda: y._frame(rgb))
         det, count, mask_d, frame_d = phase("detector (frame on the device)", lambda: y.detect_device(fd))
         depth_d = phase("depth H2D", lambda: F.upload_depth(depth, dev))
-        bb = phase("count.item + boxes D2H", lambda: det[:int(count.item()), :4].cpu().numpy().astype(np.int16))
-        packed = phase("enqueue_poses (box selection, depth lift, crops, network, Rt)",
-                       lambda: F.enqueue_poses(pred.posenet, rgb.shape, bb, pred.K, 1000.0, frame_d, mask_d, depth_d, device=dev))
-        phase("finish_poses (D2H + filter)", lambda: F.finish_poses(packed))
+        ctx = pred._frame_ctx()
+        phase("flope_frame_select (device-side box selection; count -> pinned memory)", lambda: ctx.select(0, det, count))
+        phase("flope_frame_enqueue (count wait, depth lift, crops, network, Rt, copies)", lambda: ctx.enqueue(0, frame_d, mask_d, depth_d, pred.K, 1000.0))
+        phase("flope_frame_finish (wait + reliability filter -> float64 [n,4,4])", lambda: ctx.finish(0))
     print(f"{'phase':70s} host-only ms   host+device ms")
     for k, (h, hd) in acc.items():
         print(f"{k:70s} {h / it * 1e3:9.3f}     {hd / it * 1e3:9.3f}")
