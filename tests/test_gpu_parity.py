@@ -910,8 +910,8 @@ def test_multi_frame_fusion_on_the_device_path_vs_the_oracle_pipeline(state_dict
     rng = np.random.default_rng(11)
     base = synthetic_frame(7, H, W)
     frames = []
-    for i in range(5):                    # the same scene seen again (tracks get several hits), one different scene, one empty frame
-        img = base.copy() if i != 3 else synthetic_frame(6, H, W)
+    for i in range(4):                    # the same scene seen again (tracks get a second hit), one empty frame, one different scene
+        img = base.copy() if i != 3 else synthetic_frame(6, H, W)     # (r05: four frames instead of five -- the CPU oracle is 3 s per frame)
         if i == 2:
             img = np.zeros_like(img)
         img[:4, :4] = rng.integers(0, 255, (4, 4, 3), dtype=np.uint8)      # frames are not byte-identical
@@ -920,7 +920,7 @@ def test_multi_frame_fusion_on_the_device_path_vs_the_oracle_pipeline(state_dict
         frames.append((img, depth, cam))
     fm = FlowerModel(dist_th=50, pose_predictor=pred)
     outs = list(fm.add_stream(frames, ignore=True, detectors=2))
-    assert len(outs) == 5 and outs[2] == (None, None)
+    assert len(outs) == 4 and outs[2] == (None, None)
     # ---- all-oracle side
     meas = []
     for (img, depth, cam), (pc, pw) in zip(frames, outs):
@@ -937,7 +937,7 @@ def test_multi_frame_fusion_on_the_device_path_vs_the_oracle_pipeline(state_dict
         meas.append([list(np.concatenate([w[:3, 3], Rot.from_matrix(w[:3, :3]).as_quat()])) for w in world])
     tracks = F.associate(meas, th=0.05)
     assert len(fm.kfs) == len(tracks) and list(fm.scores) == [len(t) for t in tracks]
-    assert len(meas[0]) >= 5 and max(len(t) for t in tracks) >= 3 and len(tracks) > len(meas[0])   # re-observed tracks and newcomers both occur
+    assert len(meas[0]) >= 5 and max(len(t) for t in tracks) >= 2 and len(tracks) > len(meas[0])   # re-observed tracks and newcomers both occur
     for kf, t in zip(fm.kfs, tracks):
         x, p = F.scalar_track(t)
         assert np.abs(kf.x[:3] - np.array(x[:3])).max() <= 1e-5
