@@ -61,6 +61,12 @@ struct YMultiOp {
 };
 struct YMultiP { int n, total, lds, pad_; YMultiOp op[kYMultiMax]; };
 
+// ychain_kernel (r05): up to kYChainMax CONSECUTIVE 1x1 stride-1 convs on one small map, run back to back by one grid: a workgroup owns
+// a pixel tile and pushes it through all of them (a 1x1 conv reads its own pixels only), its four waves taking the channel blocks of
+// each conv side by side; what one conv wrote for the tile is visible to the next behind a workgroup barrier.  One launch instead of n.
+constexpr int kYChainMax = 4;
+struct YChainP { int n, tiles, pad0_, pad1_; int nt[kYChainMax]; YConvP op[kYChainMax]; };
+
 struct YPoolP { const void* in; int H, W, C, ldi; void* out; int ldo; int n; };    // n (1..3) cascaded 5x5 s1 p2 max-pools, -inf border;
                                                                                    // result i -> channels [i C, (i+1) C) of out
 struct YUpP { const void* in; int H, W, C, ldi; void* out; int ldo; };             // nearest 2x: out is [2H][2W]

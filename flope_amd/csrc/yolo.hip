@@ -174,8 +174,10 @@ __device__ __forceinline__ void yconv_epilogue_unit(const YConvP& p, const int n
   }
 }
 
+// (m_base: first pixel of the wave's two pixel tiles; nblk: channel block -- yconv_body derives them from the workgroup index, the
+// chain kernel hands every wave its own channel block of one shared pixel tile)
 template <typename T, int NT, bool K3, bool SPLITK>
-__device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const int by, float* const red) {
+__device__ __forceinline__ void yconv_body_at(const YConvP& p, const int m_base, const int nblk, float* const red, const int bx, const int by) {
   typedef typename Elem<T>::frag frag;
 #ifdef FLOPE_STAG_DBG
   unsigned long long yst[5] = {0, 0, 0, 0, 0};
@@ -185,9 +187,6 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
   constexpr int MTW = 2, CB = 16 * NT, PD = 4;       // pixel tiles per wave, channels per block, pipeline depth
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
-  const int m_base = SPLITK ? bx * (16 * MTW) : (bx * 4 + wave) * (16 * MTW);
-  if (!SPLITK && m_base >= p.M) return;
-  const int nblk = by;
   const int pad = K3 ? 1 : 0;
   // r04 (in-kernel stamps, tools/clock_probe_yolo.py: a 1x1 conv on the 23 x 40 map spent 4 k cycles before its first load and 4 k in
   // the epilogue of ONE wave, of 11.5 k in all): the bias goes into the first MFMA as its C operand (no wait for it in front of the
@@ -339,6 +338,14 @@ __device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const 
     g_ydbg[slot * 8 + 5] = yrt0; g_ydbg[slot * 8 + 6] = __builtin_amdgcn_s_memrealtime(); g_ydbg[slot * 8 + 7] = (unsigned long long)p.M | ((unsigned long long)p.ksteps << 32);
   }
 #endif
+}
+
+template <typename T, int NT, bool K3, bool SPLITK>
+__device__ __forceinline__ void yconv_body(const YConvP& p, const int bx, const int by, float* const red) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m_base = SPLITK ? bx * 32 : (bx * 4 + wave) * 32;
+  if (!SPLITK && m_base >= p.M) return;
+  yconv_body_at<T, NT, K3, SPLITK>(p, m_base, by, red, bx, by);
 }
 
 template <typename T, int NT, int MTW>
@@ -850,6 +857,27 @@ __global__ __launch_bounds__(256) void ymulti_kernel(const YMultiP* __restrict__
     case 9: yconv_body<T, 4, false, true>(o.u.c, bx, by, red); break;
     case 10: yconv_body<T, 4, true, false>(o.u.c, bx, by, red); break;
     default: yconv_body<T, 4, true, true>(o.u.c, bx, by, red); break;
+  }
+}
+
+// A chain of 1x1 convs on a small map in one launch (yolo.h YChainP).  Workgroup = one 32-pixel tile; for every conv of the chain its
+// four waves take channel blocks w, w + 4, ... (the full K loop each: no split-K partial sums), then a workgroup barrier -- which on
+// this target also completes the wave's stores (vmcnt) and makes them visible to the workgroup's later loads (one CU, one L1).
+template <typename T>
+__global__ __launch_bounds__(256) void ychain_kernel(const YChainP* __restrict__ Pd) {
+  const YChainP& P = *Pd;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m_base = blockIdx.x * 32;
+  for (int i = 0; i < P.n; ++i) {
+    const YConvP& p = P.op[i];
+    const int nt = P.nt[i];
+    const int nby = (p.Cout + 16 * nt - 1) / (16 * nt);
+    for (int b = wave; b < nby; b += 4) {
+      if (nt == 1) yconv_body_at<T, 1, false, false>(p, m_base, b, nullptr, 0, b);
+      else if (nt == 2) yconv_body_at<T, 2, false, false>(p, m_base, b, nullptr, 0, b);
+      else yconv_body_at<T, 4, false, false>(p, m_base, b, nullptr, 0, b);
+    }
+    __syncthreads();
   }
 }
 
@@ -1590,6 +1618,16 @@ extern "C" int flope_ymulti_add_dw(YMultiP* m, const YDwP* p) {
 extern "C" int flope_ymulti_launch(const YMultiP* m, const YMultiP* m_dev, int dtype, void* stream) {
   if (!m_dev || m->n < 1 || m->n > kYMultiMax || m->total < 1) return (int)hipErrorInvalidValue;
   YDISPATCH(dtype, ymulti_kernel, dim3(m->total), dim3(256), m->lds, (hipStream_t)stream, m_dev);
+  return (int)hipGetLastError();
+}
+
+// can this conv be a member of a chain?  (1x1, stride 1, 16-bit output view, a small map)
+extern "C" int flope_ychain_ok(const YConvP* p, int nt) {
+  return p->k == 1 && p->stride == 1 && p->out_mode == 0 && p->M >= 1 && p->M <= 4096 && (nt == 1 || nt == 2 || nt == 4) && p->Hi == p->Ho && p->Wi == p->Wo;
+}
+extern "C" int flope_ychain_launch(const YChainP* c, const YChainP* c_dev, int dtype, void* stream) {
+  if (!c_dev || c->n < 2 || c->n > kYChainMax || c->tiles < 1) return (int)hipErrorInvalidValue;
+  YDISPATCH(dtype, ychain_kernel, dim3(c->tiles), dim3(256), 0, (hipStream_t)stream, c_dev);
   return (int)hipGetLastError();
 }
 

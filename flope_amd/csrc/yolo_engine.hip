@@ -49,6 +49,10 @@ extern "C" int flope_yread_launch(const void* src, int is_f32, int H, int W, int
 extern "C" int flope_y32_conv_launch(const YConvP* p, void* stream);
 extern "C" int flope_y32m_conv_launch(const YConvP* p, void* stream);
 extern "C" int flope_y32m_conv_ok(const YConvP* p);
+extern "C" int flope_ychain_ok(const YConvP* p, int nt);
+extern "C" int flope_ychain_launch(const YChainP* c, const YChainP* c_dev, int dtype, void* stream);
+extern "C" int flope_y32m_chain_ok(const YConvP* p);
+extern "C" int flope_y32m_chain_launch(const YChainP* c, const YChainP* c_dev, void* stream);
 extern "C" int flope_y32m_multi_add_conv(YMultiP* m, const YConvP* p);
 extern "C" int flope_y32m_multi_add_dw(YMultiP* m, const YDwP* p);
 extern "C" int flope_y32m_multi_launch(const YMultiP* m, const YMultiP* m_dev, void* stream);
@@ -84,7 +88,8 @@ struct Op {
 };
 
 // One launch of the schedule: a single op, or up to kYMultiMax independent conv / depthwise ops of one level in one grid.
-struct Launch { int op = -1; YMultiP multi; YMultiP* multi_dev = nullptr; std::vector<int> members; };
+// (r05) ... or a CHAIN of consecutive 1x1 convs on one small map, run back to back by one grid (yolo.h YChainP).
+struct Launch { int op = -1; YMultiP multi; YMultiP* multi_dev = nullptr; std::vector<int> members; YChainP chain; YChainP* chain_dev = nullptr; };
 
 struct Tap { int is_f32 = 0; const void* ptr = nullptr; int H = 0, W = 0, C = 0, ld = 0; };
 
@@ -114,6 +119,7 @@ struct flope_yolo {
   // than the overlap returned (1.31 ms; removed).  What does pay is putting the independent ops of one dependency level
   // into ONE grid (ymulti_kernel): option "batch", default on.
   int opt_batch = 1;
+  int opt_chain = 0;                                          // runs of 1x1 convs on one small map as one launch (r05: built, measured no faster -- profiles/r05_yolo_chain.txt; off)
   int opt_f32mfma = 1;                                        // float32 mode: convolutions on the exact-fp32 MFMA kernel (0: the plain fused-multiply-add kernels, its checker)
   int opt_bneck = 1;                                          // 1: Bottleneck pairs as one fused launch (ybneck_kernel); 0: two conv launches
   int opt_graph = 0;                                          // 1: flope_yolo_detect replays a captured hipGraph; 0 (default)
@@ -493,6 +499,7 @@ int launch_op(flope_yolo* e, const Op& op, hipStream_t st) {
 inline int sched_index(const flope_yolo* e) { return (e->opt_batch && (e->dtype != FLOPE_DT_F32 || e->opt_f32mfma)) ? 1 : 0; }
 
 int launch_one(flope_yolo* e, const Launch& L, hipStream_t st) {
+  if (L.chain_dev) return e->dtype == FLOPE_DT_F32 ? flope_y32m_chain_launch(&L.chain, L.chain_dev, st) : flope_ychain_launch(&L.chain, L.chain_dev, e->dtype, st);
   if (L.op >= 0) return launch_op(e, e->ops[L.op], st);
   return e->dtype == FLOPE_DT_F32 ? flope_y32m_multi_launch(&L.multi, L.multi_dev, st) : flope_ymulti_launch(&L.multi, L.multi_dev, e->dtype, st);
 }
@@ -500,7 +507,7 @@ int launch_one(flope_yolo* e, const Launch& L, hipStream_t st) {
 std::string launch_name(const flope_yolo* e, const Launch& L) {
   if (L.op >= 0) return e->ops[L.op].name;
   std::string n;
-  for (int i : L.members) n += (n.empty() ? "" : " | ") + e->ops[i].name;
+  for (int i : L.members) n += (n.empty() ? "" : (L.chain_dev ? " -> " : " | ")) + e->ops[i].name;
   return n;
 }
 
@@ -571,6 +578,45 @@ int build_schedules(flope_yolo* e) {
         e->owned.push_back(L.multi_dev);
         e->sched[1].push_back(L);
       }
+  }
+  // r05: chains.  Consecutive single launches of the level schedule that are 1x1 stride-1 convs on the same small map become ONE launch
+  // (the 23 x 40 map's conv -> conv -> conv runs cost a dependent launch each, ~8 us for ~3 us of kernel): a 1x1 conv reads nothing but
+  // its own pixel, so a workgroup can push its pixel tile through the whole run; everything else the run reads was complete before it.
+  if (e->opt_chain) {
+    std::vector<Launch> out;
+    std::vector<int> run;
+    auto chainable = [&](const Launch& L) {
+      if (L.op < 0 || L.chain_dev) return false;
+      const Op& op = e->ops[L.op];
+      if (op.kind != Op::CONV) return false;
+      return f32 ? (e->opt_f32mfma && flope_y32m_chain_ok(&op.conv) != 0) : flope_ychain_ok(&op.conv, op.nt) != 0;
+    };
+    auto flush = [&]() -> int {
+      for (size_t at = 0; at < run.size();) {
+        const size_t m = std::min(run.size() - at, (size_t)kYChainMax);
+        if (m < 2) { Launch L; L.op = run[at]; out.push_back(L); at += m; continue; }
+        Launch L;
+        memset(&L.chain, 0, sizeof L.chain);
+        L.chain.n = (int)m;
+        const int M = e->ops[run[at]].conv.M;
+        L.chain.tiles = f32 ? (M + 15) / 16 : (M + 31) / 32;
+        for (size_t k = 0; k < m; ++k) { const Op& op = e->ops[run[at + k]]; L.chain.op[k] = op.conv; L.chain.nt[k] = op.nt; L.members.push_back(run[at + k]); }
+        if (hipMalloc((void**)&L.chain_dev, sizeof(YChainP)) != hipSuccess || hipMemcpy(L.chain_dev, &L.chain, sizeof(YChainP), hipMemcpyHostToDevice) != hipSuccess)
+          return yfail(e, FLOPE_EHIP, "schedule: chain table upload failed");
+        e->owned.push_back(L.chain_dev);
+        out.push_back(L);
+        at += m;
+      }
+      run.clear();
+      return FLOPE_OK;
+    };
+    for (const Launch& L : e->sched[1]) {
+      if (chainable(L) && (run.empty() || e->ops[run.back()].conv.M == e->ops[L.op].conv.M)) { run.push_back(L.op); continue; }
+      if (int rc = flush()) return rc;
+      if (chainable(L)) run.push_back(L.op); else out.push_back(L);
+    }
+    if (int rc = flush()) return rc;
+    e->sched[1].swap(out);
   }
   return FLOPE_OK;
 }
@@ -831,7 +877,7 @@ extern "C" int flope_yolo_detect(flope_yolo_handle e, const uint8_t* frame_dev, 
   GraphKey key;
   memset(&key, 0, sizeof key);                              // the struct has tail padding and is compared bytewise
   key.frame = frame_dev; key.det = det_dev; key.count = count_dev; key.mask = mask_dev; key.conf = conf; key.iou = iou;
-  key.max_det = max_det; key.batch = e->opt_batch * 4 + e->opt_bneck + e->opt_f32mfma * 16; key.generic_attn = e->opt_generic_attn;
+  key.max_det = max_det; key.batch = e->opt_batch * 4 + e->opt_bneck + e->opt_f32mfma * 16 + e->opt_chain * 32; key.generic_attn = e->opt_generic_attn;
   hipGraphExec_t exec = nullptr;
   for (size_t i = 0; i < e->graphs.size(); ++i)
     if (memcmp(&key, &e->graphs[i].key, sizeof key) == 0) {
@@ -899,6 +945,14 @@ extern "C" int flope_yolo_set_option(flope_yolo_handle e, const char* name, int 
     return prev;
   }
   if (!strcmp(name, "batch")) { const int prev = e->opt_batch; e->opt_batch = value != 0; return prev; }
+  if (!strcmp(name, "chain")) {
+    const int prev = e->opt_chain; e->opt_chain = value != 0;
+    if (e->loaded && prev != e->opt_chain) {
+      if (int rc = build_schedules(e)) return rc;
+      drop_graphs(e);
+    }
+    return prev;
+  }
   if (!strcmp(name, "f32mfma")) { const int prev = e->opt_f32mfma; e->opt_f32mfma = value != 0; return prev; }
   if (!strcmp(name, "graph")) { const int prev = e->opt_graph; e->opt_graph = value != 0; return prev; }
   return yfail(e, FLOPE_EINVAL, std::string("flope_yolo_set_option: unknown option ") + name);
@@ -945,6 +999,9 @@ extern "C" int flope_yolo_profile(flope_yolo_handle e, const uint8_t* frame_dev,
       const Op& op = e->ops[sched[i].op];
       snprintf(line, sizeof line, "%3zu %7.2f L%-2d %s %s\n", i, u, op.level,
                op.kind == Op::DW ? "dw" : op.kind == Op::POOL ? "pool" : op.kind == Op::UP ? "up" : op.kind == Op::BNECK ? "bottleneck" : "attn", op.name.c_str());
+    } else if (sched[i].chain_dev) {
+      snprintf(line, sizeof line, "%3zu %7.2f L%-2d chain x%d (%d workgroups) %.200s\n", i, u, e->ops[sched[i].members[0]].level, sched[i].chain.n, sched[i].chain.tiles,
+               launch_name(e, sched[i]).c_str());
     } else {
       snprintf(line, sizeof line, "%3zu %7.2f L%-2d multi x%d (%d workgroups) %.200s\n", i, u, e->ops[sched[i].members[0]].level, sched[i].multi.n, sched[i].multi.total,
                launch_name(e, sched[i]).c_str());

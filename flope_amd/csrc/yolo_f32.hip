@@ -454,14 +454,14 @@ extern "C" int flope_y32_mask_low_launch(const YMaskP* p, void* stream) {
 //   ~1e-7 relative against the plain kernel above (which stays as the checker: option f32mfma = 0), not bit equality.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
+// (m0: first pixel of this wave's tile, blk: its channel block -- y32m_conv_body derives them from the workgroup index; the chain kernel
+// hands every wave its own channel block of one shared pixel tile)
 template <int NT, int MP, bool SPLITK>
-__device__ __forceinline__ void y32m_conv_body(const YConvP& p, int bx, int by, float* red) {   // red (SPLITK): 3 x 64 x NT x MP x 4 floats of LDS
+__device__ __forceinline__ void y32m_conv_body_at(const YConvP& p, const int m0, const int blk, float* red) {   // red (SPLITK): 3 x 64 x NT x MP x 4 floats of LDS
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kq = lane >> 4, c16 = lane & 15;
   constexpr int CB = 16 * NT;
   const int rows = p.out_mode == 2 ? 4 * p.dc : p.Cout;
-  const int blk = by;
-  const int m0 = (SPLITK ? bx : bx * 4 + wave) * (16 * MP);     // first pixel of this wave's tile
   const int pad = p.k == 3 ? 1 : 0, kk2 = p.k * p.k, cin = p.Cin;
   const float* const in = (const float*)p.in;
   const f32x4m* const wb = (const f32x4m*)p.w32m + (size_t)blk * p.k16steps * NT * 64 + lane;
@@ -609,6 +609,32 @@ __device__ __forceinline__ void y32m_conv_body(const YConvP& p, int bx, int by, 
 }
 
 template <int NT, int MP, bool SPLITK>
+__device__ __forceinline__ void y32m_conv_body(const YConvP& p, int bx, int by, float* red) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  y32m_conv_body_at<NT, MP, SPLITK>(p, (SPLITK ? bx : bx * 4 + wave) * (16 * MP), by, red);
+}
+
+// A chain of 1x1 convs on a small map in one launch (yolo.h YChainP; the float32 counterpart of yolo.hip's ychain_kernel): workgroup =
+// one 16-pixel tile, its four waves take the channel blocks of each conv side by side (the full K loop each), a workgroup barrier
+// between the convs.
+__global__ __launch_bounds__(256) void y32m_chain_kernel(const YChainP* __restrict__ Pd) {
+  const YChainP& P = *Pd;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = blockIdx.x * 16;
+  for (int i = 0; i < P.n; ++i) {
+    const YConvP& p = P.op[i];
+    const int nt = p.nt32m;
+    const int nby = (p.Cout + 16 * nt - 1) / (16 * nt);
+    for (int b = wave; b < nby; b += 4) {
+      if (nt == 1) y32m_conv_body_at<1, 1, false>(p, m0, b, nullptr);
+      else if (nt == 2) y32m_conv_body_at<2, 1, false>(p, m0, b, nullptr);
+      else y32m_conv_body_at<4, 1, false>(p, m0, b, nullptr);
+    }
+    __syncthreads();
+  }
+}
+
+template <int NT, int MP, bool SPLITK>
 __global__ __launch_bounds__(256) void y32m_conv_kernel(const YConvP p) {
   __shared__ __attribute__((aligned(16))) float red[SPLITK ? 3 * 64 * NT * MP * 4 : 4];
   y32m_conv_body<NT, MP, SPLITK>(p, blockIdx.x, blockIdx.y, red);
@@ -706,6 +732,17 @@ extern "C" int flope_y32m_multi_add_conv(YMultiP* m, const YConvP* p) {
   m->total += (o.nblocks + 7) / 8 * 8;
   return 0;
 }
+extern "C" int flope_y32m_chain_ok(const YConvP* p) {
+  bool splitk; int mp, nbx, nby;
+  return p->k == 1 && p->stride == 1 && p->out_mode == 0 && p->M >= 1 && p->M <= 4096 && p->Hi == p->Ho && p->Wi == p->Wo &&
+         y32m_geometry(p, &splitk, &mp, &nbx, &nby);
+}
+extern "C" int flope_y32m_chain_launch(const YChainP* c, const YChainP* c_dev, void* stream) {
+  if (!c_dev || c->n < 2 || c->n > kYChainMax || c->tiles < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(y32m_chain_kernel, dim3(c->tiles), dim3(256), 0, (hipStream_t)stream, c_dev);
+  return (int)hipGetLastError();
+}
+
 extern "C" int flope_y32m_multi_add_dw(YMultiP* m, const YDwP* p) {
   if (m->n >= kYMultiMax) return (int)hipErrorInvalidValue;
   YMultiOp& o = m->op[m->n++];

@@ -92,6 +92,7 @@ def test_batched_launches_and_graph_replay_do_not_change_a_bit(ysd):
     from flope_amd.yolo_weights import synthetic_frame
     img = synthetic_frame(9, 1080, 1920)
     y = _engine(ysd, 1080, 1920, 1280)
+    y.set_option("chain", 0)                  # (r05 option, off by default: chained 1x1 convs sum K in one wave instead of four -- their own test below)
     outs, launches = [], []
     for batch, graph in ((1, 1), (0, 0), (1, 0), (0, 1), (1, 1)):        # captured hipGraph replay and eager launches
         y.set_option("batch", batch)
@@ -107,6 +108,41 @@ def test_batched_launches_and_graph_replay_do_not_change_a_bit(ysd):
     assert len(outs[0][2]) >= 10
     assert launches[0] == launches[2] and launches[1] == launches[3] and launches[0] < launches[1] - 20, launches
     y.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_chained_1x1_convs_equal_the_separate_launches(ysd, dtype):
+    """r05: runs of consecutive 1x1 convs on one small map (C3k / SPPF / C2PSA on the 23 x 40 map, the tails of the
+    head branches) as ONE launch (option chain = 1): a workgroup pushes its pixel tile through the whole run, its waves taking the
+    channel blocks side by side with the full K loop each.  Against the separate launches (chain = 0, the default: K split over four
+    waves, partial sums added in wave order) the results agree to float32 summation order -- 16-bit maps to a rounding of a few outputs,
+    float32 maps to ~1e-6 -- the detections are the same anchors, and 9 fewer launches run.  Measured (profiles/r05_yolo_chain.txt): no
+    faster (16-bit 0.672 -> 0.667 ms per frame, float32 0.988 -> 1.058): a conv inside a chain costs what its launch did -- the store
+    drain + barrier + cold first loads between two convs are the same dependent round trips a kernel boundary is -- so it stays off."""
+    from flope_amd.yolo_weights import synthetic_frame
+    for (H, W, imgsz) in ((1080, 1920, 1280), (360, 640, 640)):
+        img = synthetic_frame(9, H, W)
+        y = _engine(ysd, H, W, imgsz, dtype)
+        names = ("8", "9", "10", "13", "16", "19", "22", "proto", "box0", "cls1", "coef2", "cls2", "box2")
+        outs, dets, launches = [], [], []
+        for chain in (1, 0):
+            assert y.set_option("chain", chain) in (0, 1)
+            dets.append(y.detect(img, 0.1))
+            outs.append({k: y.read_tensor(k).cpu() for k in names})
+            launches.append(y.launches())
+        y.set_option("chain", 1)
+        tol = 2e-3 if dtype == "f16" else 2e-6
+        for k in names:
+            assert _rel(outs[0][k], outs[1][k]) <= tol, (k, _rel(outs[0][k], outs[1][k]))
+        assert launches[0] <= launches[1] - 6, launches
+        (b1, s1, _, a1, m1), (b0, s0, _, a0, m0) = dets
+        # the same anchors (two confidences a rounding apart may sort either way), the same boxes per anchor
+        assert len(a1) >= 8 and sorted(a1.tolist()) == sorted(a0.tolist())
+        o1, o0 = np.argsort(a1), np.argsort(a0)
+        assert np.abs(b1[o1] - b0[o0]).max() <= (1.0 if dtype == "f16" else 1e-3) and np.abs(s1[o1] - s0[o0]).max() <= (2e-3 if dtype == "f16" else 1e-5)
+        assert (m1 != m0).mean() <= (2e-3 if dtype == "f16" else 1e-5)
+        y.set_option("chain", 0)
+        y.close()
 
 
 def test_lds_tile_path_equals_the_global_fragment_path(ysd):
