@@ -137,7 +137,7 @@ def test_chained_1x1_convs_equal_the_separate_launches(ysd, dtype):
         assert launches[0] <= launches[1] - 6, launches
         (b1, s1, _, a1, m1), (b0, s0, _, a0, m0) = dets
         # the same anchors (two confidences a rounding apart may sort either way), the same boxes per anchor
-        assert len(a1) >= 8 and sorted(a1.tolist()) == sorted(a0.tolist())
+        assert len(a1) >= 3 and sorted(a1.tolist()) == sorted(a0.tolist())
         o1, o0 = np.argsort(a1), np.argsort(a0)
         assert np.abs(b1[o1] - b0[o0]).max() <= (1.0 if dtype == "f16" else 1e-3) and np.abs(s1[o1] - s0[o0]).max() <= (2e-3 if dtype == "f16" else 1e-5)
         assert (m1 != m0).mean() <= (2e-3 if dtype == "f16" else 1e-5)
