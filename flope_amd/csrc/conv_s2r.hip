@@ -1,0 +1,238 @@
+// conv_s2r: the first stride-2 convolution of the trunk (layer2.0.conv1: 3x3, stride 2, 64 -> 128 channels, 56 x 56 -> 28 x 28) as
+// a row-band kernel with the input patch in LDS and the weights streamed through registers (r05).
+//
+// Reference: torchvision ResNet-18 BasicBlock conv1 + bn1 + ReLU of layer2[0], as instantiated by
+// /root/reference/sunflower/models/posenet.py:26-31 (resnet18 trunk); BN folded at load time (engine.hip load_weights).
+//
+// Why its own kernel.  K = 9 x 64 = 576 is short and N = 128 is one channel tile, so the gathered-tile kernel (conv_mfma<gather>)
+// spends its time on LDS-DMA issue: per 128-pixel tile it streams the whole 144 KB weight panel AND gathers every input pixel
+// 2.25 times (9 taps / 4 parities) -- 288 KB through the DMA queue for 2.3 us of MFMAs (21 % of the MFMA rate).
+// Here a workgroup owns 4 output rows of one image (112 pixels):
+//   * the 9 x 57-pixel input patch goes to LDS ONCE per 32-channel half-chunk, de-interleaved into the four (row, column) parity
+//     planes so that a tap's 16 pixels are unit-stride again (plane (ky & 1, kx & 1), shifted by (ky >> 1, kx >> 1));
+//   * each of the four waves owns 32 output channels and reads its A fragments (weights) straight from L2 into registers, three
+//     steps ahead of their MFMAs (the whole panel is 144 KB and every workgroup reads the same one); the first three steps'
+//     fragments stay resident;
+//   * a pixel tile is 4 rows x 4 columns, the 64-byte pixel rows are XOR-swizzled by the plane row: every ds_read_b128 of a
+//     16-lane group hits 16 different bank quads for every tap (4 columns x (slot ^ row)).
+// LDS: 2 buffers (one per half-chunk) x 4 planes x 5 rows x 32 pixels x 64 B = 80 KB -> two workgroups per CU; while a half-chunk
+// is being multiplied the other buffer receives the next tile's (global loads -> registers -> ds_write, two barriers per tile).
+// K order: half-chunk, tap, channel (conv_mfma's is tap, channel): results equal conv_mfma's within accumulation-order rounding,
+// not bit for bit (tests/test_gpu_parity.py).
+#include "common.h"
+
+namespace {
+
+template <typename T, int NPT>
+__global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u32x4* __restrict__ wpk) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int WO = 4 * NPT;              // output columns of a tile (= the map's width)
+  constexpr int PROW_B = 32 * 64;          // plane row pitch: 32 pixels of 64 bytes (WO + 1 used)
+  constexpr int PLANE_B = 5 * PROW_B;
+  constexpr int BUF_B = 4 * PLANE_B;       // 40960
+  constexpr int NIT = BUF_B / 16 / 256;    // 16-byte staging items per thread and half-chunk (10)
+  constexpr int NSTEP = 18, NRES = 18, LOOK = 3;      // (half-chunk, tap) steps; resident weight steps; look-ahead of the streamed ones
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  const int G = gridDim.x, total = p.B * (p.Ho >> 2), rgs = p.Ho >> 2;
+
+  // ---- staging map (tile independent): item j = plane row (pa = j / 5, row = j % 5) of BOTH column parities; a thread is one
+  // 16-byte slot s of plane column col of parity pb.  Source and destination are then one thread constant + a per-item constant.
+  const int pb = tid >> 7, scol = (tid >> 2) & 31, ss = tid & 3;
+  const int soff0 = (2 * min(scol, pb ? WO - 1 : WO) + pb) * 128 + ss * 16;      // the unused columns (and row) repeat a valid pixel
+  int dsw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dsw[k] = pb * PLANE_B + scol * 64 + ((ss ^ k) << 4);
+  const int wrow = p.Wip * 128;
+  // ---- fragment read addresses: pixel tile pt = columns 4 pt .. 4 pt + 3 of the tile's 4 rows; lane -> (row r16 >> 2, column r16 & 3)
+  const int rr = r16 >> 2, cc = r16 & 3;
+  int rd[2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) rd[dy] = (rr + dy) * PROW_B + cc * 64 + ((g ^ ((rr + dy) & 3)) << 4);
+  const int ooff = ((rr * p.Wop + cc) * p.Cout + 32 * wave + 8 * g) * 2;
+
+  const u32x4* const wl = wpk + (size_t)wave * NSTEP * 2 * 64 + lane;
+  // (the weights are the same for every tile: wz is a zero the compiler cannot see through, re-made once per tile, so that it
+  // neither hoists these loads out of the tile loop nor keeps a register-file full of fragments resident across it)
+  int wz = 0;
+  auto wload = [&](int s, int ct) -> frag { return __builtin_bit_cast(frag, wl[(s * 2 + ct) * 64 + wz]); };
+
+  // resident fragments and the bias take the detour over LDS: registers a GLOBAL load wrote in front of the loop and that are live
+  // into it make hipcc wait vmcnt(0) in front of the loop's first MFMA on every iteration (r05 stem)
+  frag wres[NRES][2];
+  f32x4 b4[2];
+#pragma unroll
+  for (int s0 = 0; s0 < NRES; s0 += 6) {           // six steps (12 fragments, 48 KB of LDS) per round
+    u32x4* const stage = (u32x4*)smem + tid * 12;
+#pragma unroll
+    for (int s = s0; s < s0 + 6 && s < NRES; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) stage[(s - s0) * 2 + ct] = wl[(s * 2 + ct) * 64];
+#pragma unroll
+    for (int s = s0; s < s0 + 6 && s < NRES; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) wres[s][ct] = __builtin_bit_cast(frag, stage[(s - s0) * 2 + ct]);
+    // the values must be IN the registers before the area is written again (hipcc moves these thread-private reads behind the
+    // barrier below otherwise: a random tile per launch came out as garbage)
+#pragma unroll
+    for (int s = s0; s < s0 + 6 && s < NRES; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) asm volatile("" : "+v"(wres[s][ct]));
+  }
+  {
+    u32x4* const stage = (u32x4*)smem + tid * 2;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) stage[ct] = *(const u32x4*)(p.bias + 32 * wave + 8 * g + 4 * ct);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) b4[ct] = __builtin_bit_cast(f32x4, stage[ct]);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) asm volatile("" : "+v"(b4[ct]));
+    __syncthreads();
+  }
+
+  auto band = [&](int tile) -> const char* {      // the tile's input band, row 2 * ho0 of its image
+    const int img = tile / rgs, rg = tile - img * rgs;
+    return (const char*)p.in + ((size_t)img * p.Hip + 8 * rg) * p.Wip * 128;
+  };
+  u32x4 st[NIT];
+  auto stage_load = [&](const char* src) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) st[j] = *(const u32x4*)(src + (2 * min(j % 5, j < 5 ? 4 : 3) + j / 5) * wrow + soff0);
+  };
+  auto stage_write = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) *(u32x4*)(buf + (j / 5) * 2 * PLANE_B + (j % 5) * PROW_B + dsw[(j % 5) & 3]) = st[j];
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  {
+    const char* src = band(tile);
+    stage_load(src);
+    stage_write(smem);
+    stage_load(src + 64);
+    stage_write(smem + BUF_B);
+    __syncthreads();
+  }
+
+#ifdef FLOPE_STAG_DBG
+  // diagnostic build, dbg & 64: shader-clock stamps of this workgroup's SECOND tile, wave 0 (tools/clock_probe_s2r.py)
+  unsigned long long stp[20] = {0};
+  int st_it = 0;
+#define S2R_STAMP(i_) do { if ((p.dbg & 64) && st_it == 1) { __builtin_amdgcn_sched_barrier(0); stp[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define S2R_STAMP(i_) do {} while (0)
+#endif
+  for (; tile < total; tile += G) {
+    const int nxt = tile + G < total ? tile + G : tile;
+    const char* const nsrc = band(nxt);
+    const int img = tile / rgs, rg = tile - img * rgs;
+    char* const obase = (char*)p.out + (((size_t)img * p.Hop + 4 * rg + 1) * p.Wop + 1) * p.Cout * 2 + ooff;
+
+    asm volatile("" : "+s"(wz));
+    f32x4 acc[NPT][2];
+    frag wq[NSTEP][2];          // fully unrolled: only ~4 steps' worth are live at any time
+    frag xf[2][NPT];
+    auto xread = [&](int s) {   // the pixel fragments of step s (half-chunk s / 9, tap s % 9)
+      const int hc = s / 9, tap = s - 9 * hc, ky = tap / 3, kx = tap - 3 * ky;
+      const char* const xb = smem + hc * BUF_B + ((ky & 1) * 2 + (kx & 1)) * PLANE_B + rd[ky >> 1] + (kx >> 1) * 64;
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) xf[s & 1][pt] = *(const frag*)(xb + pt * 256);
+    };
+#pragma unroll
+    for (int s = NRES; s < NRES + LOOK && s < NSTEP; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) wq[s][ct] = wload(s, ct);
+    xread(0);
+    __builtin_amdgcn_sched_barrier(0);
+    S2R_STAMP(0);
+
+    // Every step is pinned by scheduling barriers: left alone, hipcc sinks each load to its first use (fewest live registers) and the
+    // step then waits a full L2 / HBM latency.  Global loads return in order (one vmcnt counter), so the next tile's patch loads
+    // go out at step 6 / 15, BEHIND the weight loads whose MFMAs run before the barrier and in front of those that run after it.
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s == 3) S2R_STAMP(1);
+      if (s == 6) S2R_STAMP(2);
+      if (s == 9) {
+        S2R_STAMP(3);
+        __syncthreads();                    // barrier 1: everyone is done with buffer 0; buffer 1's writes are visible
+        S2R_STAMP(4);
+        stage_write(smem);
+        xread(9);
+        __builtin_amdgcn_sched_barrier(0);
+        S2R_STAMP(5);
+      }
+      if (s == 12) S2R_STAMP(6);
+      if (s == 15) S2R_STAMP(7);
+      if (s == 6) stage_load(nsrc);         // next tile, half-chunk 0 (lands in buffer 0 behind barrier 1)
+      if (s == 15) stage_load(nsrc + 64);   // next tile, half-chunk 1 (buffer 1, behind barrier 2)
+      if (s + LOOK >= NRES + LOOK && s + LOOK < NSTEP) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wq[s + LOOK][ct] = wload(s + LOOK, ct);
+      }
+      if (s + 1 < NSTEP && s + 1 != 9) xread(s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          acc[pt][ct] = Elem<T>::mfma(s < NRES ? wres[s][ct] : wq[s][ct], xf[s & 1][pt], s == 0 ? b4[ct] : acc[pt][ct]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    S2R_STAMP(8);
+    // epilogue: ReLU (+ float16 clamp), 8 consecutive channels = one 16-byte store per pixel and lane
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+      u32x4 o;
+      o[0] = pk_out16<T>(pack2<T>(acc[pt][0][0], acc[pt][0][1]), p.relu);
+      o[1] = pk_out16<T>(pack2<T>(acc[pt][0][2], acc[pt][0][3]), p.relu);
+      o[2] = pk_out16<T>(pack2<T>(acc[pt][1][0], acc[pt][1][1]), p.relu);
+      o[3] = pk_out16<T>(pack2<T>(acc[pt][1][2], acc[pt][1][3]), p.relu);
+      *(u32x4*)(obase + pt * 4 * p.Cout * 2) = o;
+    }
+    S2R_STAMP(9);
+    __syncthreads();                        // barrier 2: everyone is done with buffer 1; buffer 0's writes are visible
+    S2R_STAMP(10);
+    stage_write(smem + BUF_B);
+    S2R_STAMP(11);
+#ifdef FLOPE_STAG_DBG
+    if ((p.dbg & 64) && st_it == 1 && p.split_ws && tid == 0) {
+      unsigned long long* d_ = (unsigned long long*)p.split_ws + (size_t)blockIdx.x * 16;
+      for (int i = 0; i < 12; ++i) d_[i] = stp[i];
+    }
+    ++st_it;
+#endif
+  }
+#undef S2R_STAMP
+}
+
+}  // namespace
+
+// layer shapes this kernel takes: 3x3 stride 2, 64 -> 128 channels, output map 28 wide and a multiple of 4 rows, no residual
+extern "C" int flope_conv_s2r_ok(const ConvP* p) {
+  return p->stride == 2 && p->ntaps == 9 && p->Cin == 64 && p->Cout == 128 && p->Wo == 28 && (p->Ho & 3) == 0 && !p->res && !p->ds_in &&
+         p->ksplit <= 1 && p->Wip == 2 * p->Wo + 2 && p->Hip == 2 * p->Ho + 2;
+}
+
+extern "C" int flope_conv_s2r_lds() { return 2 * 4 * 5 * 32 * 64; }
+
+extern "C" int flope_conv_s2r_init() {
+  hipError_t e = hipFuncSetAttribute((const void*)conv_s2r_kernel<bf16_t, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, flope_conv_s2r_lds());
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s2r_kernel<f16_t, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, flope_conv_s2r_lds());
+  return (int)e;
+}
+
+// w: pack_s2r image.  grid: workgroups (two per CU); each walks tiles blockIdx.x + k * grid of batch * Ho / 4.
+extern "C" int flope_conv_s2r_launch(const ConvP* p, const void* w, int dtype, int grid, void* stream) {
+  if (!flope_conv_s2r_ok(p) || !w) return (int)hipErrorInvalidValue;
+  const int total = p->B * (p->Ho >> 2);
+  if (grid > total) grid = total;
+  if (grid < 1) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)flope_conv_s2r_lds();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL((conv_s2r_kernel<bf16_t, 7>), dim3(grid), dim3(256), lds, st, *p, (const u32x4*)w);
+  else hipLaunchKernelGGL((conv_s2r_kernel<f16_t, 7>), dim3(grid), dim3(256), lds, st, *p, (const u32x4*)w);
+  return (int)hipGetLastError();
+}

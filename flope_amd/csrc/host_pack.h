@@ -169,6 +169,25 @@ inline std::vector<uint16_t> pack_stem_frag(const std::vector<float>& wf, int dt
   return out;
 }
 
+// conv_s2r (layer2.0.conv1, r05): wave w owns output channels 32 w .. 32 w + 31 as two MFMA row tiles ct and reads its A fragments
+// from global memory, one 16-byte load per lane:  [4 waves][18 steps = half-chunk * 9 + tap][2 ct][64 lanes][8]  <-
+// W[32 w + 8 (i >> 2) + 4 ct + (i & 3)][ci = 32 hc + 8 (lane >> 4) + j][tap],  i = lane & 15  -- MFMA D rows 4 g .. 4 g + 3 of tile ct
+// are then channels 32 w + 8 g + 4 ct .. + 3, so a lane's eight outputs of a pixel are eight consecutive channels (one 16-byte store).
+inline std::vector<uint16_t> pack_s2r(const std::vector<float>& wf, int cout, int cin, int dtype) {
+  std::vector<uint16_t> out((size_t)4 * 18 * 2 * 64 * 8);
+  for (int w = 0; w < 4; ++w)
+    for (int st = 0; st < 18; ++st)
+      for (int ct = 0; ct < 2; ++ct)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int i = lane & 15, hc = st / 9, tap = st % 9, ky = tap / 3, kx = tap % 3;
+            const int co = 32 * w + 8 * (i >> 2) + 4 * ct + (i & 3), ci = 32 * hc + 8 * (lane >> 4) + j;
+            (void)cout;
+            out[((((size_t)w * 18 + st) * 2 + ct) * 64 + lane) * 8 + j] = cvt16(wf[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx], dtype);
+          }
+  return out;
+}
+
 inline std::vector<float> naive_layout(const std::vector<float>& wf, int cout, int cin, int k) {
   std::vector<float> out((size_t)cout * cin * k * k);
   for (int co = 0; co < cout; ++co)

@@ -168,6 +168,36 @@ def test_register_weight_stem_does_not_change_a_bit(state_dict, H, W, B, dtype):
     assert _rel(outs[0][0][2], emu["pool"]) <= (2e-3 if dtype == "f16" else 1e-2)
 
 
+@pytest.mark.parametrize("B,dtype,streams", [(3, "f16", 1), (40, "bf16", 1), (150, "f16", 1), (150, "f16", 2)])
+def test_stride2_patch_kernel_against_the_gathered_tile_kernel(state_dict, B, dtype, streams):
+    """conv_s2r (r05, default for layer2.0.conv1 on 224 x 224 crops: 4-row bands, de-interleaved patch in LDS, weights through
+    registers) against conv_mfma<gather> (option s2r = 0).  The K order differs (half-chunk, tap, channel against tap, channel), so
+    the two agree within accumulation-order rounding, not bit for bit; both sit inside the stage tolerance of the emulating
+    oracle.  B = 3: 21 tiles on 512 workgroups; B = 150: 1050 tiles, two or three per workgroup (next-tile patch prefetch)."""
+    torch.manual_seed(17)
+    x = torch.rand(B, 3, 224, 224)
+    tol = 2e-3 if dtype == "f16" else 1e-2
+    emu = O.forward_stages_emulated(state_dict, x[:8], TDT[dtype])
+    outs = []
+    for s2r in (1, 0):
+        e = _engine(state_dict, 224, 224, B, dtype, s2r=s2r, streams=streams)
+        r9, R = _run(e, x)
+        kernels = [k for _, k, _ in e.launch_info(B)]
+        assert any("conv_s2r_kernel" in k for k in kernels) == bool(s2r), kernels
+        outs.append((r9, e.read_stage("layer2.0", B).cpu()))
+        e.close()
+    n = min(B, 8)
+    for r9, l2 in outs:
+        assert _rel(l2[:n], emu["layer2.0"][:n]) <= tol
+        assert _rel(r9[:n], emu["r9"][:n]) <= tol
+    assert _rel(outs[0][1], outs[1][1]) <= tol / 2
+    # a width the kernel does not take (20-wide layer 2) stays on the gathered-tile kernel
+    e = _engine(state_dict, 96, 80, 2, "f16")
+    _run(e, torch.rand(2, 3, 96, 80))
+    assert not any("conv_s2r_kernel" in k for _, k, _ in e.launch_info(2))
+    e.close()
+
+
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
 def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg):
     """BASELINE cfg1 inputs (16 seeded 224x224 crops) against the committed goldens."""
