@@ -23,28 +23,38 @@
 
 namespace {
 
+#define GLDS16(gptr, lptr)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),          \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
 template <typename T, int NPT>
 __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u32x4* __restrict__ wpk) {
   typedef typename Elem<T>::frag frag;
   constexpr int WO = 4 * NPT;              // output columns of a tile (= the map's width)
   constexpr int PROW_B = 32 * 64;          // plane row pitch: 32 pixels of 64 bytes (WO + 1 used)
   constexpr int PLANE_B = 5 * PROW_B;
-  constexpr int BUF_B = 4 * PLANE_B;       // 40960
-  constexpr int NIT = BUF_B / 16 / 256;    // 16-byte staging items per thread and half-chunk (10)
-  constexpr int NSTEP = 18, NRES = 18, LOOK = 3;      // (half-chunk, tap) steps; resident weight steps; look-ahead of the streamed ones
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF_B = 4 * PLANE_B;       // 40960: one unit = one 32-channel half-chunk of one tile's patch
+  constexpr int NSTEP = 18;                // (half-chunk, tap) steps of a tile
+  constexpr int NPIECE = 9;                // LDS-DMA pieces (1 KB each) per wave and unit: plane rows (pa, row) = (0, 0..4), (1, 0..3)
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // 4 unit buffers
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   const int G = gridDim.x, total = p.B * (p.Ho >> 2), rgs = p.Ho >> 2;
 
-  // ---- staging map (tile independent): item j = plane row (pa = j / 5, row = j % 5) of BOTH column parities; a thread is one
-  // 16-byte slot s of plane column col of parity pb.  Source and destination are then one thread constant + a per-item constant.
-  const int pb = tid >> 7, scol = (tid >> 2) & 31, ss = tid & 3;
-  const int soff0 = (2 * min(scol, pb ? WO - 1 : WO) + pb) * 128 + ss * 16;      // the unused columns (and row) repeat a valid pixel
-  int dsw[4];
+  // ---- LDS-DMA map (tile independent).  Wave w moves the half-rows (column parity pb = w >> 1, half h = w & 1: plane columns
+  // 16 h .. 16 h + 15) of every plane row; lane -> plane column 16 h + (lane >> 2), 16-byte LDS slot lane & 3.  The DMA writes a
+  // wave's 1 KB linearly, so the row swizzle is applied on the SOURCE side: LDS slot sl of plane row `row` receives source slot
+  // sl ^ (row & 3).  The unused columns (and the fifth row of the odd planes, skipped) repeat a valid pixel.
+  const int dpb = wave >> 1, dh = wave & 1, dcol = 16 * dh + (lane >> 2), dsl = lane & 3;
+  int dso[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) dsw[k] = pb * PLANE_B + scol * 64 + ((ss ^ k) << 4);
+  for (int k = 0; k < 4; ++k) dso[k] = (2 * min(dcol, dpb ? WO - 1 : WO) + dpb) * 128 + ((dsl ^ k) << 4);
   const int wrow = p.Wip * 128;
+  char* const dbase = smem + dpb * PLANE_B + dh * 1024;
+  // piece k of a unit: plane row (pa = k / 5, row = k % 5)
+#define S2R_PIECE(src_, buf_, k_)                                                                              \
+  GLDS16((src_) + (2 * ((k_) % 5) + (k_) / 5) * wrow + dso[((k_) % 5) & 3], dbase + (buf_) * BUF_B + ((k_) / 5) * 2 * PLANE_B + ((k_) % 5) * PROW_B)
+
   // ---- fragment read addresses: pixel tile pt = columns 4 pt .. 4 pt + 3 of the tile's 4 rows; lane -> (row r16 >> 2, column r16 & 3)
   const int rr = r16 >> 2, cc = r16 & 3;
   int rd[2];
@@ -52,31 +62,27 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
   for (int dy = 0; dy < 2; ++dy) rd[dy] = (rr + dy) * PROW_B + cc * 64 + ((g ^ ((rr + dy) & 3)) << 4);
   const int ooff = ((rr * p.Wop + cc) * p.Cout + 32 * wave + 8 * g) * 2;
 
+  // ---- this wave's weights: all 36 A fragments (18 steps x 2 channel tiles) and the bias stay in registers for the whole launch.
+  // They take the detour over LDS: registers a GLOBAL load wrote in front of the loop and that are live into it make hipcc wait
+  // vmcnt(0) in front of the loop's first MFMA on every iteration (r05 stem).
   const u32x4* const wl = wpk + (size_t)wave * NSTEP * 2 * 64 + lane;
-  // (the weights are the same for every tile: wz is a zero the compiler cannot see through, re-made once per tile, so that it
-  // neither hoists these loads out of the tile loop nor keeps a register-file full of fragments resident across it)
-  int wz = 0;
-  auto wload = [&](int s, int ct) -> frag { return __builtin_bit_cast(frag, wl[(s * 2 + ct) * 64 + wz]); };
-
-  // resident fragments and the bias take the detour over LDS: registers a GLOBAL load wrote in front of the loop and that are live
-  // into it make hipcc wait vmcnt(0) in front of the loop's first MFMA on every iteration (r05 stem)
-  frag wres[NRES][2];
+  frag wres[NSTEP][2];
   f32x4 b4[2];
 #pragma unroll
-  for (int s0 = 0; s0 < NRES; s0 += 6) {           // six steps (12 fragments, 48 KB of LDS) per round
+  for (int s0 = 0; s0 < NSTEP; s0 += 6) {           // six steps (12 fragments, 48 KB of LDS) per round
     u32x4* const stage = (u32x4*)smem + tid * 12;
 #pragma unroll
-    for (int s = s0; s < s0 + 6 && s < NRES; ++s)
+    for (int s = s0; s < s0 + 6; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) stage[(s - s0) * 2 + ct] = wl[(s * 2 + ct) * 64];
 #pragma unroll
-    for (int s = s0; s < s0 + 6 && s < NRES; ++s)
+    for (int s = s0; s < s0 + 6; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) wres[s][ct] = __builtin_bit_cast(frag, stage[(s - s0) * 2 + ct]);
-    // the values must be IN the registers before the area is written again (hipcc moves these thread-private reads behind the
-    // barrier below otherwise: a random tile per launch came out as garbage)
+    // the values must be IN the registers before the area is written again (hipcc moves these thread-private reads behind a later
+    // barrier otherwise: a random tile per launch came out as garbage)
 #pragma unroll
-    for (int s = s0; s < s0 + 6 && s < NRES; ++s)
+    for (int s = s0; s < s0 + 6; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) asm volatile("" : "+v"(wres[s][ct]));
   }
@@ -88,33 +94,30 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
     for (int ct = 0; ct < 2; ++ct) b4[ct] = __builtin_bit_cast(f32x4, stage[ct]);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) asm volatile("" : "+v"(b4[ct]));
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                  // the staging area is the patch image from here on
 
-  auto band = [&](int tile) -> const char* {      // the tile's input band, row 2 * ho0 of its image
+  auto band = [&](int tile) -> const char* {        // the tile's input band, row 2 * ho0 of its image (a tile past the end: the last one)
+    tile = min(tile, total - 1);
     const int img = tile / rgs, rg = tile - img * rgs;
     return (const char*)p.in + ((size_t)img * p.Hip + 8 * rg) * p.Wip * 128;
-  };
-  u32x4 st[NIT];
-  auto stage_load = [&](const char* src) {
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) st[j] = *(const u32x4*)(src + (2 * min(j % 5, j < 5 ? 4 : 3) + j / 5) * wrow + soff0);
-  };
-  auto stage_write = [&](char* buf) {
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) *(u32x4*)(buf + (j / 5) * 2 * PLANE_B + (j % 5) * PROW_B + dsw[(j % 5) & 3]) = st[j];
   };
 
   int tile = blockIdx.x;
   if (tile >= total) return;
-  {
-    const char* src = band(tile);
-    stage_load(src);
-    stage_write(smem);
-    stage_load(src + 64);
-    stage_write(smem + BUF_B);
-    __syncthreads();
-  }
+  // Units: u = 2 * (tile of this workgroup's walk) + half-chunk, in buffer u & 3.  The pieces of unit u + 3 go out during unit u
+  // (one per step, into the buffer unit u - 1 has just left); in front of unit u a wave waits for its own pieces of unit u --
+  // `vmcnt(18)`: loads complete in order, and the 18 pieces of units u + 1 and u + 2 are the only loads issued behind them
+  // (stores that are still in flight only make the count more conservative) -- and the barrier makes everyone's visible.
+  const char* b0 = band(tile);
+  const char* b1 = band(tile + G);
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) S2R_PIECE(b0, 0, k);
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) S2R_PIECE(b0 + 64, 1, k);
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) S2R_PIECE(b1, 2, k);
 
 #ifdef FLOPE_STAG_DBG
   // diagnostic build, dbg & 64: shader-clock stamps of this workgroup's SECOND tile, wave 0 (tools/clock_probe_s2r.py)
@@ -124,62 +127,54 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
 #else
 #define S2R_STAMP(i_) do {} while (0)
 #endif
+  int par = 0;                                       // tile parity: this tile's units sit in buffers 2 par, 2 par + 1
   for (; tile < total; tile += G) {
-    const int nxt = tile + G < total ? tile + G : tile;
-    const char* const nsrc = band(nxt);
+    const char* const b2 = band(tile + 2 * G);
     const int img = tile / rgs, rg = tile - img * rgs;
     char* const obase = (char*)p.out + (((size_t)img * p.Hop + 4 * rg + 1) * p.Wop + 1) * p.Cout * 2 + ooff;
+    char* const xbuf = smem + par * 2 * BUF_B;
 
-    asm volatile("" : "+s"(wz));
     f32x4 acc[NPT][2];
-    frag wq[NSTEP][2];          // fully unrolled: only ~4 steps' worth are live at any time
     frag xf[2][NPT];
-    auto xread = [&](int s) {   // the pixel fragments of step s (half-chunk s / 9, tap s % 9)
+    auto xaddr = [&](int s) -> const char* {   // pixel fragments of step s (half-chunk s / 9, tap s % 9), pixel tile 0
       const int hc = s / 9, tap = s - 9 * hc, ky = tap / 3, kx = tap - 3 * ky;
-      const char* const xb = smem + hc * BUF_B + ((ky & 1) * 2 + (kx & 1)) * PLANE_B + rd[ky >> 1] + (kx >> 1) * 64;
-#pragma unroll
-      for (int pt = 0; pt < NPT; ++pt) xf[s & 1][pt] = *(const frag*)(xb + pt * 256);
+      return xbuf + hc * BUF_B + ((ky & 1) * 2 + (kx & 1)) * PLANE_B + rd[ky >> 1] + (kx >> 1) * 64;
     };
-#pragma unroll
-    for (int s = NRES; s < NRES + LOOK && s < NSTEP; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) wq[s][ct] = wload(s, ct);
-    xread(0);
-    __builtin_amdgcn_sched_barrier(0);
     S2R_STAMP(0);
-
-    // Every step is pinned by scheduling barriers: left alone, hipcc sinks each load to its first use (fewest live registers) and the
-    // step then waits a full L2 / HBM latency.  Global loads return in order (one vmcnt counter), so the next tile's patch loads
-    // go out at step 6 / 15, BEHIND the weight loads whose MFMAs run before the barrier and in front of those that run after it.
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
+      if (s == 0 || s == 9) {
+        if (s == 9) S2R_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (s == 9) S2R_STAMP(4);
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) xf[s & 1][pt] = *(const frag*)(xaddr(s) + pt * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 9) S2R_STAMP(5);
+      }
       if (s == 3) S2R_STAMP(1);
       if (s == 6) S2R_STAMP(2);
-      if (s == 9) {
-        S2R_STAMP(3);
-        __syncthreads();                    // barrier 1: everyone is done with buffer 0; buffer 1's writes are visible
-        S2R_STAMP(4);
-        stage_write(smem);
-        xread(9);
-        __builtin_amdgcn_sched_barrier(0);
-        S2R_STAMP(5);
-      }
       if (s == 12) S2R_STAMP(6);
       if (s == 15) S2R_STAMP(7);
-      if (s == 6) stage_load(nsrc);         // next tile, half-chunk 0 (lands in buffer 0 behind barrier 1)
-      if (s == 15) stage_load(nsrc + 64);   // next tile, half-chunk 1 (buffer 1, behind barrier 2)
-      if (s + LOOK >= NRES + LOOK && s + LOOK < NSTEP) {
+      // the pieces of unit u + 3: during half-chunk 0 the next tile's half-chunk 1 (buffer of this tile's parity ^ 1, second),
+      // during half-chunk 1 the tile after next's half-chunk 0 (this tile's own first buffer, which the barrier has just freed)
+      const char* const dsrc = s < 9 ? b1 + 64 : b2;
+      const int dbuf = s < 9 ? (par ^ 1) * 2 + 1 : par * 2;
+      const bool more = s != 8 && s != 17;           // the first reads of a unit wait for its barrier
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wq[s + LOOK][ct] = wload(s + LOOK, ct);
+      for (int pt = 0; pt < NPT; ++pt) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = Elem<T>::mfma(wres[s][ct], xf[s & 1][pt], s == 0 ? b4[ct] : acc[pt][ct]);
+        if (more) xf[(s + 1) & 1][pt] = *(const frag*)(xaddr(s + 1) + pt * 256);
+        if (pt == 1) S2R_PIECE(dsrc, dbuf, s % 9);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (pt == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-      if (s + 1 < NSTEP && s + 1 != 9) xread(s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          acc[pt][ct] = Elem<T>::mfma(s < NRES ? wres[s][ct] : wq[s][ct], xf[s & 1][pt], s == 0 ? b4[ct] : acc[pt][ct]);
-      __builtin_amdgcn_sched_barrier(0);
     }
     S2R_STAMP(8);
     // epilogue: ReLU (+ float16 clamp), 8 consecutive channels = one 16-byte store per pixel and lane
@@ -193,9 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
       *(u32x4*)(obase + pt * 4 * p.Cout * 2) = o;
     }
     S2R_STAMP(9);
-    __syncthreads();                        // barrier 2: everyone is done with buffer 1; buffer 0's writes are visible
     S2R_STAMP(10);
-    stage_write(smem + BUF_B);
     S2R_STAMP(11);
 #ifdef FLOPE_STAG_DBG
     if ((p.dbg & 64) && st_it == 1 && p.split_ws && tid == 0) {
@@ -204,8 +197,12 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
     }
     ++st_it;
 #endif
+    b1 = b2;
+    par ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead pieces of the tiles past the end land before the LDS is released
 #undef S2R_STAMP
+#undef S2R_PIECE
 }
 
 }  // namespace
@@ -216,7 +213,7 @@ extern "C" int flope_conv_s2r_ok(const ConvP* p) {
          p->ksplit <= 1 && p->Wip == 2 * p->Wo + 2 && p->Hip == 2 * p->Ho + 2;
 }
 
-extern "C" int flope_conv_s2r_lds() { return 2 * 4 * 5 * 32 * 64; }
+extern "C" int flope_conv_s2r_lds() { return 4 * 4 * 5 * 32 * 64; }
 
 extern "C" int flope_conv_s2r_init() {
   hipError_t e = hipFuncSetAttribute((const void*)conv_s2r_kernel<bf16_t, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, flope_conv_s2r_lds());
