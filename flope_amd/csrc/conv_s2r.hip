@@ -20,6 +20,7 @@
 // K order: half-chunk, tap, channel (conv_mfma's is tap, channel): results equal conv_mfma's within accumulation-order rounding,
 // not bit for bit (tests/test_gpu_parity.py).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -31,35 +32,54 @@ template <typename T, int NPT>
 __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u32x4* __restrict__ wpk) {
   typedef typename Elem<T>::frag frag;
   constexpr int WO = 4 * NPT;              // output columns of a tile (= the map's width)
-  constexpr int PROW_B = 32 * 64;          // plane row pitch: 32 pixels of 64 bytes (WO + 1 used)
-  constexpr int PLANE_B = 5 * PROW_B;
-  constexpr int BUF_B = 4 * PLANE_B;       // 40960: one unit = one 32-channel half-chunk of one tile's patch
+  constexpr int PROW_B = 32 * 128;         // plane row pitch: 32 pixels (WO + 1 used) of 128 bytes (all 64 channels: whole cache lines)
+  constexpr int BUF_B = 18 * PROW_B;       // 73728: planes (0,0), (0,1) with 5 rows, (1,0), (1,1) with 4
   constexpr int NSTEP = 18;                // (half-chunk, tap) steps of a tile
-  constexpr int NPIECE = 9;                // LDS-DMA pieces (1 KB each) per wave and unit: plane rows (pa, row) = (0, 0..4), (1, 0..3)
-  extern __shared__ __attribute__((aligned(16))) char smem[];          // 4 unit buffers
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 tile buffers
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   const int G = gridDim.x, total = p.B * (p.Ho >> 2), rgs = p.Ho >> 2;
 
-  // ---- LDS-DMA map (tile independent).  Wave w moves the half-rows (column parity pb = w >> 1, half h = w & 1: plane columns
-  // 16 h .. 16 h + 15) of every plane row; lane -> plane column 16 h + (lane >> 2), 16-byte LDS slot lane & 3.  The DMA writes a
-  // wave's 1 KB linearly, so the row swizzle is applied on the SOURCE side: LDS slot sl of plane row `row` receives source slot
-  // sl ^ (row & 3).  The unused columns (and the fifth row of the odd planes, skipped) repeat a valid pixel.
-  const int dpb = wave >> 1, dh = wave & 1, dcol = 16 * dh + (lane >> 2), dsl = lane & 3;
-  int dso[4];
+  // ---- LDS image of a tile's patch.  Pixel (row, col) of plane (pa, pb) = input pixel (2 row + pa, 2 col + pb) of the band, 128
+  // bytes = eight 16-byte slots; slot q (channels 8 q .. 8 q + 7) sits at position q ^ sw(row, col),
+  //     sw = ((col >> 1) & 1) << 2 | (row & 3).
+  // A fragment read's 16-lane group covers 4 rows x 4 consecutive columns of one slot: its bank quad (address / 16) % 16 =
+  // 8 (col & 1) + position, and (col & 1, (col >> 1) & 1, row & 3) takes all 16 values -> conflict-free for every tap shift.
+  //
+  // ---- LDS-DMA map (tile independent).  A piece = one wave-instruction = 8 pixels x 128 B = eight WHOLE cache lines (r05: with
+  // 64-byte half-lines -- one 32-channel half-chunk per buffer -- every line was fetched twice and the launch ran at the rate
+  // the L1's outstanding misses allow).  Wave w moves, of every plane row (pa, row), column parity pb = w >> 1 and the two column
+  // octets 2 (w & 1) + oo; lane -> column 8 octet + (lane >> 3), LDS position lane & 7.  The DMA writes a wave's 1 KB linearly, so
+  // the swizzle is applied on the SOURCE side: position q receives source slot q ^ sw.  Unused columns repeat a valid pixel.
+  const int dpb = wave >> 1;
+  int dso[2][4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) dso[k] = (2 * min(dcol, dpb ? WO - 1 : WO) + dpb) * 128 + ((dsl ^ k) << 4);
+  for (int oo = 0; oo < 2; ++oo) {
+    const int col = 8 * (2 * (wave & 1) + oo) + (lane >> 3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      dso[oo][k] = (2 * min(col, dpb ? WO - 1 : WO) + dpb) * 128 + (((lane & 7) ^ ((((col >> 1) & 1) << 2) | k)) << 4);
+  }
   const int wrow = p.Wip * 128;
-  char* const dbase = smem + dpb * PLANE_B + dh * 1024;
-  // piece k of a unit: plane row (pa = k / 5, row = k % 5)
+  char* const dbase = smem + dpb * 5 * PROW_B + (wave & 1) * 2048;
+  // piece k = 0 .. 17 of a tile: plane row (pa = (k >> 1) / 5, row = (k >> 1) % 5), octet oo = k & 1
+#define S2R_PA(k_) (((k_) >> 1) / 5)
+#define S2R_ROW(k_) (((k_) >> 1) % 5)
 #define S2R_PIECE(src_, buf_, k_)                                                                              \
-  GLDS16((src_) + (2 * ((k_) % 5) + (k_) / 5) * wrow + dso[((k_) % 5) & 3], dbase + (buf_) * BUF_B + ((k_) / 5) * 2 * PLANE_B + ((k_) % 5) * PROW_B)
+  GLDS16((src_) + (2 * S2R_ROW(k_) + S2R_PA(k_)) * wrow + dso[(k_) & 1][S2R_ROW(k_) & 3],                      \
+         dbase + (buf_) * BUF_B + S2R_PA(k_) * (10 * PROW_B - dpb * PROW_B) + S2R_ROW(k_) * PROW_B + ((k_) & 1) * 1024)
+  // (plane offsets: (0,0) 0, (0,1) 5 rows, (1,0) 10 rows, (1,1) 14 rows: pa adds 10 rows - pb)
 
   // ---- fragment read addresses: pixel tile pt = columns 4 pt .. 4 pt + 3 of the tile's 4 rows; lane -> (row r16 >> 2, column r16 & 3)
   const int rr = r16 >> 2, cc = r16 & 3;
-  int rd[2];
+  int rd[2][2][2];                          // [half-chunk][row shift ky >> 1][column shift kx >> 1]
 #pragma unroll
-  for (int dy = 0; dy < 2; ++dy) rd[dy] = (rr + dy) * PROW_B + cc * 64 + ((g ^ ((rr + dy) & 3)) << 4);
+  for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+        rd[hc][dy][dx] = (rr + dy) * PROW_B + (cc + dx) * 128 + (((4 * hc + g) ^ (((((cc + dx) >> 1) & 1) << 2) | ((rr + dy) & 3))) << 4);
   const int ooff = ((rr * p.Wop + cc) * p.Cout + 32 * wave + 8 * g) * 2;
 
   // ---- this wave's weights: all 36 A fragments (18 steps x 2 channel tiles) and the bias stay in registers for the whole launch.
@@ -103,21 +123,15 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
     const int img = tile / rgs, rg = tile - img * rgs;
     return (const char*)p.in + ((size_t)img * p.Hip + 8 * rg) * p.Wip * 128;
   };
+  auto outp = [&](int tile) -> char* {
+    const int img = tile / rgs, rg = tile - img * rgs;
+    return (char*)p.out + (((size_t)img * p.Hop + 4 * rg + 1) * p.Wop + 1) * p.Cout * 2 + ooff;
+  };
 
   int tile = blockIdx.x;
   if (tile >= total) return;
-  // Units: u = 2 * (tile of this workgroup's walk) + half-chunk, in buffer u & 3.  The pieces of unit u + 3 go out during unit u
-  // (one per step, into the buffer unit u - 1 has just left); in front of unit u a wave waits for its own pieces of unit u --
-  // `vmcnt(18)`: loads complete in order, and the 18 pieces of units u + 1 and u + 2 are the only loads issued behind them
-  // (stores that are still in flight only make the count more conservative) -- and the barrier makes everyone's visible.
-  const char* b0 = band(tile);
-  const char* b1 = band(tile + G);
 #pragma unroll
-  for (int k = 0; k < NPIECE; ++k) S2R_PIECE(b0, 0, k);
-#pragma unroll
-  for (int k = 0; k < NPIECE; ++k) S2R_PIECE(b0 + 64, 1, k);
-#pragma unroll
-  for (int k = 0; k < NPIECE; ++k) S2R_PIECE(b1, 2, k);
+  for (int k = 0; k < 18; ++k) S2R_PIECE(band(tile), 0, k);
 
 #ifdef FLOPE_STAG_DBG
   // diagnostic build, dbg & 64: shader-clock stamps of this workgroup's SECOND tile, wave 0 (tools/clock_probe_s2r.py)
@@ -127,82 +141,100 @@ __global__ __launch_bounds__(256, 1) void conv_s2r_kernel(const ConvP p, const u
 #else
 #define S2R_STAMP(i_) do {} while (0)
 #endif
-  int par = 0;                                       // tile parity: this tile's units sit in buffers 2 par, 2 par + 1
-  for (; tile < total; tile += G) {
-    const char* const b2 = band(tile + 2 * G);
-    const int img = tile / rgs, rg = tile - img * rgs;
-    char* const obase = (char*)p.out + (((size_t)img * p.Hop + 4 * rg + 1) * p.Wop + 1) * p.Cout * 2 + ooff;
-    char* const xbuf = smem + par * 2 * BUF_B;
 
-    f32x4 acc[NPT][2];
+  // One tile: barrier; 18 steps of 14 MFMAs.  Beside the MFMAs: the next step's 7 fragment reads, in steps 0 .. 8 the 18 pieces of the
+  // NEXT tile's patch (into the other buffer, which the barrier has just freed), in steps 9 .. 15 the PREVIOUS tile's epilogue
+  // (pack, ReLU, one 16-byte store per pixel tile).  The wait in front of the barrier is a plain vmcnt(0): this wave's pieces of
+  // this tile went out at least nine steps ago, and the youngest stores a whole tile ago.
+  f32x4 acc[2][NPT][2];
+  // (the first tile has no previous one: its epilogue slot stores the other accumulator set's junk to this tile's OWN outputs, which
+  // the same lanes overwrite with the results one tile later -- no branch in the step stream)
+  char* oprev = outp(tile);
+  auto body = [&](auto cur_) {
+    constexpr int CUR = decltype(cur_)::value;
+    const char* const nsrc = band(tile + G);
+    char* const xbuf = smem + CUR * BUF_B;
     frag xf[2][NPT];
     auto xaddr = [&](int s) -> const char* {   // pixel fragments of step s (half-chunk s / 9, tap s % 9), pixel tile 0
       const int hc = s / 9, tap = s - 9 * hc, ky = tap / 3, kx = tap - 3 * ky;
-      return xbuf + hc * BUF_B + ((ky & 1) * 2 + (kx & 1)) * PLANE_B + rd[ky >> 1] + (kx >> 1) * 64;
+      return xbuf + ((ky & 1) * 10 + (kx & 1) * (5 - (ky & 1))) * PROW_B + rd[hc][ky >> 1][kx >> 1];
     };
     S2R_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    S2R_STAMP(1);
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) xf[0][pt] = *(const frag*)(xaddr(0) + pt * 512);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      if (s == 0 || s == 9) {
-        if (s == 9) S2R_STAMP(3);
-        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        if (s == 9) S2R_STAMP(4);
-#pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) xf[s & 1][pt] = *(const frag*)(xaddr(s) + pt * 256);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s == 9) S2R_STAMP(5);
-      }
-      if (s == 3) S2R_STAMP(1);
-      if (s == 6) S2R_STAMP(2);
-      if (s == 12) S2R_STAMP(6);
-      if (s == 15) S2R_STAMP(7);
-      // the pieces of unit u + 3: during half-chunk 0 the next tile's half-chunk 1 (buffer of this tile's parity ^ 1, second),
-      // during half-chunk 1 the tile after next's half-chunk 0 (this tile's own first buffer, which the barrier has just freed)
-      const char* const dsrc = s < 9 ? b1 + 64 : b2;
-      const int dbuf = s < 9 ? (par ^ 1) * 2 + 1 : par * 2;
-      const bool more = s != 8 && s != 17;           // the first reads of a unit wait for its barrier
+      if (s == 9) S2R_STAMP(2);
 #pragma unroll
       for (int pt = 0; pt < NPT; ++pt) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = Elem<T>::mfma(wres[s][ct], xf[s & 1][pt], s == 0 ? b4[ct] : acc[pt][ct]);
-        if (more) xf[(s + 1) & 1][pt] = *(const frag*)(xaddr(s + 1) + pt * 256);
-        if (pt == 1) S2R_PIECE(dsrc, dbuf, s % 9);
+        for (int ct = 0; ct < 2; ++ct) acc[CUR][pt][ct] = Elem<T>::mfma(wres[s][ct], xf[s & 1][pt], s == 0 ? b4[ct] : acc[CUR][pt][ct]);
+        if (s + 1 < NSTEP) xf[(s + 1) & 1][pt] = *(const frag*)(xaddr(s + 1) + pt * 512);
+        if (s < 9 && pt < 2) S2R_PIECE(nsrc, CUR ^ 1, 2 * s + pt);
+        if (s >= 9 && s - 9 == pt) {
+          u32x4 o;
+          o[0] = pk_out16<T>(pack2<T>(acc[CUR ^ 1][pt][0][0], acc[CUR ^ 1][pt][0][1]), p.relu);
+          o[1] = pk_out16<T>(pack2<T>(acc[CUR ^ 1][pt][0][2], acc[CUR ^ 1][pt][0][3]), p.relu);
+          o[2] = pk_out16<T>(pack2<T>(acc[CUR ^ 1][pt][1][0], acc[CUR ^ 1][pt][1][1]), p.relu);
+          o[3] = pk_out16<T>(pack2<T>(acc[CUR ^ 1][pt][1][2], acc[CUR ^ 1][pt][1][3]), p.relu);
+          *(u32x4*)(oprev + pt * 4 * p.Cout * 2) = o;
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (pt == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (s < 9 && pt < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
-    S2R_STAMP(8);
-    // epilogue: ReLU (+ float16 clamp), 8 consecutive channels = one 16-byte store per pixel and lane
-#pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) {
-      u32x4 o;
-      o[0] = pk_out16<T>(pack2<T>(acc[pt][0][0], acc[pt][0][1]), p.relu);
-      o[1] = pk_out16<T>(pack2<T>(acc[pt][0][2], acc[pt][0][3]), p.relu);
-      o[2] = pk_out16<T>(pack2<T>(acc[pt][1][0], acc[pt][1][1]), p.relu);
-      o[3] = pk_out16<T>(pack2<T>(acc[pt][1][2], acc[pt][1][3]), p.relu);
-      *(u32x4*)(obase + pt * 4 * p.Cout * 2) = o;
-    }
-    S2R_STAMP(9);
-    S2R_STAMP(10);
-    S2R_STAMP(11);
+    S2R_STAMP(3);
 #ifdef FLOPE_STAG_DBG
     if ((p.dbg & 64) && st_it == 1 && p.split_ws && tid == 0) {
       unsigned long long* d_ = (unsigned long long*)p.split_ws + (size_t)blockIdx.x * 16;
-      for (int i = 0; i < 12; ++i) d_[i] = stp[i];
+      for (int i = 0; i < 4; ++i) d_[i] = stp[i];
     }
     ++st_it;
 #endif
-    b1 = b2;
-    par ^= 1;
+    oprev = outp(tile);
+    tile += G;
+  };
+  for (;;) {
+    body(std::integral_constant<int, 0>{});
+    if (tile >= total) {
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        u32x4 o;
+        o[0] = pk_out16<T>(pack2<T>(acc[0][pt][0][0], acc[0][pt][0][1]), p.relu);
+        o[1] = pk_out16<T>(pack2<T>(acc[0][pt][0][2], acc[0][pt][0][3]), p.relu);
+        o[2] = pk_out16<T>(pack2<T>(acc[0][pt][1][0], acc[0][pt][1][1]), p.relu);
+        o[3] = pk_out16<T>(pack2<T>(acc[0][pt][1][2], acc[0][pt][1][3]), p.relu);
+        *(u32x4*)(oprev + pt * 4 * p.Cout * 2) = o;
+      }
+      break;
+    }
+    body(std::integral_constant<int, 1>{});
+    if (tile >= total) {
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        u32x4 o;
+        o[0] = pk_out16<T>(pack2<T>(acc[1][pt][0][0], acc[1][pt][0][1]), p.relu);
+        o[1] = pk_out16<T>(pack2<T>(acc[1][pt][0][2], acc[1][pt][0][3]), p.relu);
+        o[2] = pk_out16<T>(pack2<T>(acc[1][pt][1][0], acc[1][pt][1][1]), p.relu);
+        o[3] = pk_out16<T>(pack2<T>(acc[1][pt][1][2], acc[1][pt][1][3]), p.relu);
+        *(u32x4*)(oprev + pt * 4 * p.Cout * 2) = o;
+      }
+      break;
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead pieces of the tiles past the end land before the LDS is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead pieces of the tile past the end land before the LDS is released
 #undef S2R_STAMP
 #undef S2R_PIECE
+#undef S2R_PA
+#undef S2R_ROW
 }
 
 }  // namespace
@@ -213,7 +245,7 @@ extern "C" int flope_conv_s2r_ok(const ConvP* p) {
          p->ksplit <= 1 && p->Wip == 2 * p->Wo + 2 && p->Hip == 2 * p->Ho + 2;
 }
 
-extern "C" int flope_conv_s2r_lds() { return 4 * 4 * 5 * 32 * 64; }
+extern "C" int flope_conv_s2r_lds() { return 2 * 18 * 32 * 128; }
 
 extern "C" int flope_conv_s2r_init() {
   hipError_t e = hipFuncSetAttribute((const void*)conv_s2r_kernel<bf16_t, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, flope_conv_s2r_lds());

@@ -32,18 +32,17 @@ while time.time() - t0 < 2.0:
 idx = [i for i, (layer, k, _) in enumerate(e.launch_info(B)) if "layer2.0.conv1" in layer][0]
 conv = [n for n in range(40)]
 buf = np.zeros(512 * 16, dtype=np.uint64)
-names = ["steps 0-2", "steps 3-5", "steps 6-8 (+ patch loads issue)", "barrier 1", "patch write + reads of step 9", "steps 9-11", "steps 12-14",
-         "steps 15-17 (+ patch loads issue)", "epilogue", "barrier 2", "patch write"]
+names = ["wait + barrier", "steps 0-8 (+ next patch pieces)", "steps 9-17 (+ previous epilogue)"]
 for ci in range(20):
     rc = e.lib.flope_debug_read_ws(e.handle, buf.ctypes.data_as(C.c_void_p), C.c_size_t(ci * 1048576), C.c_size_t(buf.nbytes))
     assert rc == 0
     r = buf.reshape(-1, 16).astype(np.int64)
-    ok = (r[:, 0] > 0) & (r[:, 11] > r[:, 0]) & (r[:, 11] - r[:, 0] < 10**7)
+    ok = (r[:, 0] > 0) & (r[:, 3] > r[:, 0]) & (r[:, 3] - r[:, 0] < 10**7) & (r[:, 4] == 0)
     if ok.sum() < 100:
         continue
     d = r[ok]
     print(f"region {ci}: {int(ok.sum())} workgroups; median cycles, second tile, wave 0 (MFMA floor: 224 per step alone, 448 with the co-resident workgroup)")
     for k, n in enumerate(names):
         print(f"  {n:40s} {np.median(d[:, k + 1] - d[:, k]):8.0f}")
-    print(f"  {'tile':40s} {np.median(d[:, 11] - d[:, 0]):8.0f}")
+    print(f"  {'tile':40s} {np.median(d[:, 3] - d[:, 0]):8.0f}")
 e.close()
