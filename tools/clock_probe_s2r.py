@@ -32,17 +32,17 @@ while time.time() - t0 < 2.0:
 idx = [i for i, (layer, k, _) in enumerate(e.launch_info(B)) if "layer2.0.conv1" in layer][0]
 conv = [n for n in range(40)]
 buf = np.zeros(512 * 16, dtype=np.uint64)
-names = ["wait + barrier", "steps 0-8 (+ next patch pieces)", "steps 9-17 (+ previous epilogue)"]
+names = ["steps 0-8 (+ next patch pieces)", "steps 9-17", "wait for the pieces", "epilogue", "barrier"]
 for ci in range(20):
     rc = e.lib.flope_debug_read_ws(e.handle, buf.ctypes.data_as(C.c_void_p), C.c_size_t(ci * 1048576), C.c_size_t(buf.nbytes))
     assert rc == 0
     r = buf.reshape(-1, 16).astype(np.int64)
-    ok = (r[:, 0] > 0) & (r[:, 3] > r[:, 0]) & (r[:, 3] - r[:, 0] < 10**7) & (r[:, 4] == 0)
+    ok = (r[:, 0] > 0) & (r[:, 5] > r[:, 0]) & (r[:, 5] - r[:, 0] < 10**7) & (r[:, 6] == 0)
     if ok.sum() < 100:
         continue
     d = r[ok]
-    print(f"region {ci}: {int(ok.sum())} workgroups; median cycles, second tile, wave 0 (MFMA floor: 224 per step alone, 448 with the co-resident workgroup)")
+    print(f"region {ci}: {int(ok.sum())} workgroups; median cycles, second tile, wave 0 (wave 0: 8 MFMAs per step = 128 cycles alone; the SIMD's two waves together 14 = 224)")
     for k, n in enumerate(names):
         print(f"  {n:40s} {np.median(d[:, k + 1] - d[:, k]):8.0f}")
-    print(f"  {'tile':40s} {np.median(d[:, 3] - d[:, 0]):8.0f}")
+    print(f"  {'tile':40s} {np.median(d[:, 5] - d[:, 0]):8.0f}")
 e.close()
