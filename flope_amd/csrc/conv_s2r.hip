@@ -70,7 +70,11 @@ __global__ __launch_bounds__(512, 1) void conv_s2r_kernel(const ConvP p, const u
          dbase + (buf_) * BUF_B + ((k_) / 5) * (10 * PROW_B - dpb * PROW_B) + ((k_) % 5) * PROW_B)
 
   // ---- fragment read addresses: pixel tile pt = columns 4 pt .. 4 pt + 3 of the tile's 4 rows; lane -> (row r16 >> 2, column r16 & 3)
-  const int rr = r16 >> 2, cc = r16 & 3;
+  // (a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: 8 lanes of slot g with r16 in
+  // {0-3, 12-15} and 8 lanes of slot g ^ 1 with r16 in {4-11}.  The first set takes the even columns, the second the odd ones:
+  // bit 3 of the bank quad separates them, (row, column >> 1) the eight pixels inside each.)
+  const int i8 = r16 < 4 ? r16 : (r16 < 12 ? r16 - 4 : r16 - 8);
+  const int rr = i8 >> 1, cc = 2 * (i8 & 1) + ((r16 >= 4 && r16 < 12) ? 1 : 0);
   int rd[2][2][2];                          // [half-chunk][row shift ky >> 1][column shift kx >> 1]
 #pragma unroll
   for (int hc = 0; hc < 2; ++hc)

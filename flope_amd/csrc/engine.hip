@@ -110,7 +110,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_stem_r = 1, opt_s2r = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_stem_r = 1, opt_s2r = 1, opt_s2r_grid = 0;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -566,6 +566,7 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
+  else if (!strcmp(name, "s2r_grid")) { prev = e->opt_s2r_grid; e->opt_s2r_grid = value; return prev; }   // workgroups of a conv_s2r launch (0: one per CU)
   else if (!strcmp(name, "s2r")) { prev = e->opt_s2r; e->opt_s2r = value != 0; return prev; }   // 1: layer2.0.conv1 on conv_s2r (224^2 crops), 0: conv_mfma<gather>
   else if (!strcmp(name, "w4")) { prev = e->opt_w4; e->opt_w4 = value != 0; return prev; }
   else if (!strcmp(name, "w4cw")) { prev = e->opt_w4cw; e->opt_w4cw = value < 0 ? 0 : (value > 64 ? 64 : value); return prev; }   // conv_w4 class walk: tiles per persistent workgroup aimed at (0 / 1 = one tile per workgroup)
@@ -868,7 +869,7 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
         if ((e->opt_dbg & 64) && e->split_ws) p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
         SMARK();
         c.last_kernel = "conv_s2r_kernel<4rows x28>"; c.last_detail.clear();
-        K_TRY(e, c.name.c_str(), flope_conv_s2r_launch(&p, c.w_s2r, dt, e->num_cus, stream));
+        K_TRY(e, c.name.c_str(), flope_conv_s2r_launch(&p, c.w_s2r, dt, e->opt_s2r_grid > 0 ? e->opt_s2r_grid : e->num_cus, stream));
         continue;
       }
       SMARK();
