@@ -26,9 +26,15 @@
 
 namespace {
 
-#define GLDS16(gptr, lptr)                                                                         \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),          \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// LDS-DMA piece by inline assembly: 16 bytes per lane from the lane's own global address to LDS address m0 + 16 * lane.
+// Not the builtin: while hipcc's wait-count pass knows of an outstanding global_load_lds it turns EVERY wait it inserts into a
+// wait for zero -- `s_waitcnt lgkmcnt(0)` in front of each step's first MFMA, i.e. behind the fragment reads issued a few cycles
+// before (r05: one exposed LDS round trip per step).  Hidden from it, the fragment waits are counted (`lgkmcnt(N)`); the pieces'
+// own completion is this kernel's business either way (manual `s_waitcnt vmcnt` + barrier, "memory" clobbers on both).
+__device__ __forceinline__ void glds16(const char* gptr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+}
+#define GLDS16(gptr, lptr) glds16((gptr), (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)(lptr)))
 
 template <typename T, int NPT>
 __global__ __launch_bounds__(512, 1) void conv_s2r_kernel(const ConvP p, const u32x4* __restrict__ wpk) {

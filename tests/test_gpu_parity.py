@@ -198,6 +198,31 @@ def test_stride2_patch_kernel_against_the_gathered_tile_kernel(state_dict, B, dt
     e.close()
 
 
+@pytest.mark.parametrize("B,dtype,streams", [(3, "f16", 1), (40, "bf16", 1), (150, "f16", 2)])
+def test_register_weight_layer2_kernel_against_conv_w4(state_dict, B, dtype, streams):
+    """conv_s1r (r05, default for layer2.1.conv1 / conv2 on 224 x 224 crops: K split over wave pairs, all weights in registers, partial
+    sums swapped through LDS; conv2 with the residual) against conv_w4 (option s1r = 0): different K order, so equal within
+    accumulation-order rounding; both inside the emulating oracle's stage tolerance.  B = 150: 1050 bands on 256 workgroups
+    (four or five per workgroup: patch double-buffering, swap-slot reuse)."""
+    torch.manual_seed(19)
+    x = torch.rand(B, 3, 224, 224)
+    tol = 2e-3 if dtype == "f16" else 1e-2
+    n = min(B, 8)
+    emu = O.forward_stages_emulated(state_dict, x[:n], TDT[dtype])
+    outs = []
+    for s1r in (1, 0):
+        e = _engine(state_dict, 224, 224, B, dtype, s1r=s1r, streams=streams)
+        r9, R = _run(e, x)
+        kernels = [k for _, k, _ in e.launch_info(B)]
+        assert sum("conv_s1r_kernel" in k for k in kernels) == (2 if s1r else 0), kernels
+        outs.append((r9, e.read_stage("layer2.1", B).cpu()))
+        e.close()
+    for r9, l2 in outs:
+        assert _rel(l2[:n], emu["layer2.1"][:n]) <= tol
+        assert _rel(r9[:n], emu["r9"][:n]) <= tol
+    assert _rel(outs[0][1], outs[1][1]) <= tol / 2
+
+
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
 def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg):
     """BASELINE cfg1 inputs (16 seeded 224x224 crops) against the committed goldens."""
