@@ -27,7 +27,7 @@ namespace {
 // before (r05: one exposed LDS round trip per step).  Hidden from it, the fragment waits are counted (`lgkmcnt(N)`); the pieces'
 // own completion is this kernel's business either way (manual `s_waitcnt vmcnt` + barrier, "memory" clobbers on both).
 __device__ __forceinline__ void glds16(const char* gptr, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory");
 }
 #define GLDS16(gptr, lptr) glds16((gptr), (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)(lptr)))
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
     char* const xbuf = smem + cur * BUF_B + P0 * 256;
     const int nbuf = cur ^ 1;
     f32x4 acc[NP][2];
-    frag xf[3][NP];                 // fragments are read TWO steps ahead (one step = 128 / 96 cycles of this wave's MFMAs is less than a loaded LDS round trip)
+    frag xf[2][NP];
     S1R_STAMP(FIRST ? 0 : 5);
     auto xaddr = [&](int s) -> const char* {   // pixel fragments of step s (half-chunk s / 9, tap s % 9), the sub-tile's first pixel tile
       const int hc = s / 9, tap = s - 9 * hc, ky = tap / 3, kx = tap - 3 * ky;
@@ -140,23 +140,18 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
     };
 #pragma unroll
     for (int pt = 0; pt < NP; ++pt) xf[0][pt] = *(const frag*)(xaddr(0) + pt * 256);
-#pragma unroll
-    for (int pt = 0; pt < NP; ++pt) xf[1][pt] = *(const frag*)(xaddr(1) + pt * 256);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      // the SIMD's two waves (kh 0 and kh 1 of two pairs) take turns at the higher issue priority, step by step: left alone the older
-      // wave runs at its solo speed, finishes 2 k cycles early and idles at the barrier while the other one runs alone at 60 %
-      if (((s & 1) ^ KH) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int pt = 0; pt < NP; ++pt) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          acc[pt][ct] = Elem<T>::mfma(wres[s][ct], xf[s % 3][pt], s == 0 ? (KH ? zero4 : b4[ct]) : acc[pt][ct]);
-        if (s + 2 < NSTEP) xf[(s + 2) % 3][pt] = *(const frag*)(xaddr(s + 2) + pt * 256);
+          acc[pt][ct] = Elem<T>::mfma(wres[s][ct], xf[s & 1][pt], s == 0 ? (KH ? zero4 : b4[ct]) : acc[pt][ct]);
+        if (s + 1 < NSTEP) xf[(s + 1) & 1][pt] = *(const frag*)(xaddr(s + 1) + pt * 256);
         if (FIRST && s < 3 && pt < 2) S1R_PIECE(nsrc, nbuf, 2 * s + pt);       // the next band's six pieces
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        if (s + 2 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if (FIRST && s < 3 && pt < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }

@@ -32,7 +32,7 @@ namespace {
 // before (r05: one exposed LDS round trip per step).  Hidden from it, the fragment waits are counted (`lgkmcnt(N)`); the pieces'
 // own completion is this kernel's business either way (manual `s_waitcnt vmcnt` + barrier, "memory" clobbers on both).
 __device__ __forceinline__ void glds16(const char* gptr, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory");
 }
 #define GLDS16(gptr, lptr) glds16((gptr), (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)(lptr)))
 

@@ -117,7 +117,7 @@ def test_conflict_free_patch_image_and_4_wave_kernel_do_not_change_a_bit(state_d
     if (H, W) != (224, 224):                               # the class walk needs M % 224 == 0 and the small tile heights their patch fit: 224 x 224 only
         cfgs = [dict(w4mt=7, w4cw=0), dict(w4mt=8), dict(w4mt=0, w4cw=0), dict(), dict(w4=0)]
     for cfg in cfgs:
-        opts = dict(streams=1, ksplit=0)                   # (split-K sends small launches to conv_stag: covered by test_split_k_small_batches)
+        opts = dict(streams=1, ksplit=0, s1r=0)            # (split-K sends small launches to conv_stag: covered by test_split_k_small_batches; s1r = 0: layer2.1 on conv_w4 too -- conv_s1r has its own test)
         opts.update(cfg)
         e = _engine(state_dict, H, W, B, dtype, **opts)
         r9, R = _run(e, x)

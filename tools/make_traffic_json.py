@@ -23,6 +23,7 @@ def label(k):
     if "conv_stag" in k and "Li64E" in k: return "conv_stag_kernel<8rows x64>"
     if "conv_stag" in k: return "conv_stag_kernel<256x128>"
     if "conv_gstag" in k: return "conv_gstag_kernel<256x128,s2>"
+    if "conv_s1r" in k: return "conv_s1r_kernel<4rows x28>"
     if "conv_s2r" in k: return "conv_s2r_kernel<4rows x28>"
     if "conv_mfma" in k: return "conv_mfma_kernel<128x128,gather,ring2>"
     if "stem_pool" in k: return "stem_pool_kernel"

@@ -19,6 +19,7 @@ def fam(k):
     if "conv_stag" in k and "Li64E" in k: return "conv_stag<8 rows x 64> (layer 1)", 59.19
     if "conv_stag" in k: return "conv_stag<256x128> (layers 2-4, 3x3 s1; three of nine carry the folded 1x1 shortcut)", 59.19 + 3.29 / 3
     if "conv_gstag" in k: return "conv_gstag<256x128,s2> (3x3 s2, Cin >= 128)", 29.59
+    if "conv_s1r" in k: return "conv_s1r<4 rows x 28> (layer2.1.conv1 / conv2: 3x3 s1, 128 -> 128; K split over wave pairs, weights in registers)", 59.19
     if "conv_s2r" in k: return "conv_s2r<4 rows x 28> (layer2.0.conv1: 3x3 s2, 64 -> 128; 8 waves, weights in registers)", 29.59
     if "conv_mfma" in k: return "conv_mfma<128x128,gather> (3x3 s2, Cin = 64)", 29.59
     if "stem_pool" in k: return "stem_pool (conv1 7x7 s2 + bn + relu + maxpool)", 60.42
@@ -48,7 +49,7 @@ def pmc(sub, name):
 fetch, write, mfma = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE"), pmc("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES")
 gf = {}
 for k in list(dur):
-    for probe in ("conv_w4", "conv_r4", "conv_stag_kernelIDF16_Li5ELi64E", "conv_stag_kernelIDF16_Li4ELi128E", "conv_gstag", "conv_s2r", "conv_mfma", "stem_pool", "fc1", "fc2", "avgpool"):
+    for probe in ("conv_w4", "conv_r4", "conv_stag_kernelIDF16_Li5ELi64E", "conv_stag_kernelIDF16_Li4ELi128E", "conv_gstag", "conv_s1r", "conv_s2r", "conv_mfma", "stem_pool", "fc1", "fc2", "avgpool"):
         f, g = fam(probe)
         if f == k: gf[k] = g
 print("| kernel | launches / forward | avg µs | GFLOP / launch | TFLOP/s | of 2.5 PF | MFMA pipe busy | HBM MB / launch | HBM GB/s (of 8 TB/s) |")
