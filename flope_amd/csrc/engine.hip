@@ -36,9 +36,6 @@ extern "C" int flope_conv_w4_init();
 extern "C" int flope_conv_r4_init();
 extern "C" int flope_conv_r4_ok(const ConvP* p);
 extern "C" int flope_conv_r4_launch(const ConvP* p, int dtype, int grid_blocks, void* stream);
-extern "C" int flope_conv_l1r_init();
-extern "C" int flope_conv_l1r_ok(const ConvP* p);
-extern "C" int flope_conv_l1r_launch(const ConvP* p, const void* w, int dtype, int grid, void* stream);
 extern "C" int flope_conv_s1r_init();
 extern "C" int flope_conv_s1r_ok(const ConvP* p);
 extern "C" int flope_conv_s1r_launch(const ConvP* p, const void* w, int dtype, int grid, void* stream);
@@ -84,7 +81,6 @@ struct Conv {
   void* w_stag = nullptr;      // conv_stag image (16-bit), 3x3 s1 Cout >= 128 only
   void* w_s2r = nullptr;       // conv_s2r fragment image (16-bit), the 3x3 stride-2 64 -> 128 conv only
   void* w_s1r = nullptr;       // conv_s1r fragment image (16-bit), the 3x3 stride-1 128 -> 128 convs
-  void* w_l1r = nullptr;       // conv_l1r fragment image (16-bit), the 3x3 stride-1 64 -> 64 convs
   int stag = 0, stag_patch_bytes = 0, nseg = 1; size_t stag_lds = 0;
   int w4_patch[9] = {0};               // conv_w4 on 32 mt-pixel tiles, mt = 4..7: patch rounds of such a tile (0: not available)
   float* w_naive = nullptr;    // [ky][kx][ci][cout]
@@ -118,7 +114,7 @@ struct flope_engine {
   float *feat = nullptr, *hidden = nullptr, *W1 = nullptr, *W1p = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
   float* r9_scratch = nullptr;
   bool weights_loaded = false;
-  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_stem_r = 1, opt_s2r = 1, opt_s2r_grid = 0, opt_s1r = 1, opt_l1r = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
+  int opt_patch = 1, opt_bm256 = 1, opt_profile = 0, opt_nbuf = 2, opt_dbg = 0, opt_ldspad = 0, opt_fuse_stem = 1, opt_streams = 2, opt_persist = 0, num_cus = 256, opt_stag = 3, cur_slices = 1, plan_slices = 1, cur_batch = 1, opt_rows_grid = 0, opt_split = 0, opt_dsfuse = 1, opt_ksplit = 1, opt_fc1_packed = 1, opt_gstag = 1, opt_rowseg = 1, opt_stem_persist = 1, opt_skew = 1, opt_reslds = 1, opt_prio = 0, opt_r4 = 1, opt_w4cw = 4, opt_w4cwf = 0, opt_fc2_k4 = 1, opt_w4mt = 0, opt_w4mtlo = 0, opt_lag = 20, opt_w4 = 1, opt_stem_r = 1, opt_s2r = 1, opt_s2r_grid = 0, opt_s1r = 1;   // w4: 0 = conv_stag for the flat 256 x 128 tiles, 1 = conv_w4 (4 waves); w4cw: class walk of conv_w4 (persistent workgroups), tiles per workgroup aimed at (0 = one tile per workgroup)
   float* split_ws = nullptr; size_t split_ws_bytes = 0;   // fp32 partial sums of the split-K path (small batches)   // stag: 0 off, 1 Cout >= 128 layers, 2 also the 64-channel layer (512 x 64 tiles), 3 (default) 64-channel layer as 8-row bands where the shape allows
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -442,7 +438,6 @@ extern "C" int flope_create(int device_id, int height, int width, int max_batch,
     if (s == 0) s = flope_conv_r4_init();
     if (s == 0) s = flope_conv_s2r_init();
     if (s == 0) s = flope_conv_s1r_init();
-    if (s == 0) s = flope_conv_l1r_init();
     if (s != 0) { int rc = fail(nullptr, FLOPE_EHIP, std::string("kernel attribute setup: ") + hipGetErrorString((hipError_t)s)); flope_destroy(e); return rc; }
   }
   const size_t B = (size_t)max_batch;
@@ -536,7 +531,7 @@ extern "C" int flope_destroy(flope_handle e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
-  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_s2r) hipFree(c.w_s2r); if (c.w_s1r) hipFree(c.w_s1r); if (c.w_l1r) hipFree(c.w_l1r); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.bias_fused) hipFree(c.bias_fused); }
+  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_s2r) hipFree(c.w_s2r); if (c.w_s1r) hipFree(c.w_s1r); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.bias_fused) hipFree(c.bias_fused); }
   void* singles[] = {e->stem_in, e->stem_q, e->stem_w, e->stem_w2, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
@@ -576,7 +571,6 @@ extern "C" int flope_set_option(flope_handle e, const char* name, int value) {
   else if (!strcmp(name, "rowseg")) { prev = e->opt_rowseg; e->opt_rowseg = value != 0; }
   else if (!strcmp(name, "skew")) { prev = e->opt_skew; e->opt_skew = value != 0; }
   else if (!strcmp(name, "r4")) { prev = e->opt_r4; e->opt_r4 = value != 0; return prev; }
-  else if (!strcmp(name, "l1r")) { prev = e->opt_l1r; e->opt_l1r = value != 0; return prev; }   // 1: layer 1 on conv_l1r (224^2 crops), 0: conv_r4
   else if (!strcmp(name, "s1r")) { prev = e->opt_s1r; e->opt_s1r = value != 0; return prev; }   // 1: layer2.1.conv1 / conv2 on conv_s1r (224^2 crops), 0: conv_w4
   else if (!strcmp(name, "s2r_grid")) { prev = e->opt_s2r_grid; e->opt_s2r_grid = value; return prev; }   // workgroups of a conv_s2r launch (0: one per CU)
   else if (!strcmp(name, "s2r")) { prev = e->opt_s2r; e->opt_s2r = value != 0; return prev; }   // 1: layer2.0.conv1 on conv_s2r (224^2 crops), 0: conv_mfma<gather>
@@ -631,7 +625,6 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
     else {
       if ((rc = upload(e, pack_conv(wf, c.cout, c.cin, c.k, e->dtype), &c.w_packed)) != 0) return rc;
       if (c.k == 3 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
-      if (c.k == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64 && (rc = upload(e, pack_l1r(wf, c.cin, e->dtype), &c.w_l1r)) != 0) return rc;
       if (c.k == 3 && c.stride == 1 && c.cin == 128 && c.cout == 128 && (rc = upload(e, pack_s1r(wf, c.cin, e->dtype), &c.w_s1r)) != 0) return rc;
       if (c.k == 3 && c.stride == 2 && c.cin == 64 && c.cout == 128 && (rc = upload(e, pack_s2r(wf, c.cout, c.cin, e->dtype), &c.w_s2r)) != 0) return rc;
       if (c.k == 1 && c.cout >= 128 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32_1x1(wf, c.cout, c.cin, e->dtype), &c.w_ds_stag)) != 0) return rc;
@@ -780,13 +773,6 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
                                                                  : e->num_cus);
       gridb -= gridb % p.ntiles;
       if (gridb < p.ntiles) gridb = p.ntiles;
-      // r05: layer 1 with all weights in registers, two waves per SIMD (conv_l1r.hip)
-      if (c.stag == 2 && e->opt_l1r && c.w_l1r && c.nseg <= 1 && !(e->opt_dbg & 128) && flope_conv_l1r_ok(&p)) {
-        SMARK();
-        c.last_kernel = "conv_l1r_kernel<8rows x56>"; c.last_detail.clear();
-        K_TRY(e, c.name.c_str(), flope_conv_l1r_launch(&p, c.w_l1r, dt, e->num_cus, stream));
-        continue;
-      }
       // r03: layer 1 (64 -> 64 on the 56-wide map) on the 4-wave row-band kernel (conv_r4.hip)
       if (c.stag == 2 && e->opt_r4 && c.nseg <= 1 && !(e->opt_dbg & 128) && flope_conv_r4_ok(&p)) {
         fastdiv_magic((unsigned)(p.Wip + 2), &p.mg_pitch, &p.sh_pitch);
@@ -1121,7 +1107,6 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     else if (c.stag == 3) snprintf(k, sizeof k, "conv_gstag_kernel<256x128,s2>");
     else if (e->opt_s1r && c.w_s1r && c.ds_conv < 0 && c.stag == 1 && c.wout == 28 && c.hout % 4 == 0) snprintf(k, sizeof k, "conv_s1r_kernel<4rows x28>");
     else if (w4_eligible(e, c)) snprintf(k, sizeof k, "conv_w4_kernel<256x128>");
-    else if (c.stag == 2 && e->opt_l1r && c.w_l1r && c.nseg <= 1 && c.wout == 56 && c.hout % 8 == 0) snprintf(k, sizeof k, "conv_l1r_kernel<8rows x56>");
     else if (c.stag == 2 && e->opt_r4 && c.nseg <= 1 && c.cin == 64 && c.cout == 64 && c.wout == 56 && c.hout % 8 == 0) snprintf(k, sizeof k, "conv_r4_kernel<8rows x56>");
     else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));
     else if (e->opt_s2r && c.w_s2r && c.wout == 28 && c.hout % 4 == 0) snprintf(k, sizeof k, "conv_s2r_kernel<4rows x28>");

@@ -206,22 +206,6 @@ inline std::vector<uint16_t> pack_s1r(const std::vector<float>& wf, int cin, int
   return out;
 }
 
-// conv_l1r (layer 1, r05): wave (cg, pixel group) owns output channels 32 cg .. 32 cg + 31 over the whole K = 9 x 64:
-// [2 cg][18 steps = half-chunk * 9 + tap][2 ct][64 lanes][8]  <-  W[32 cg + 8 (i >> 2) + 4 ct + (i & 3)][ci = 32 hc + 8 (lane >> 4) + j][tap]
-inline std::vector<uint16_t> pack_l1r(const std::vector<float>& wf, int cin, int dtype) {
-  std::vector<uint16_t> out((size_t)2 * 18 * 2 * 64 * 8);
-  for (int cg = 0; cg < 2; ++cg)
-    for (int st = 0; st < 18; ++st)
-      for (int ct = 0; ct < 2; ++ct)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int i = lane & 15, hc = st / 9, tap = st % 9, ky = tap / 3, kx = tap % 3;
-            const int co = 32 * cg + 8 * (i >> 2) + 4 * ct + (i & 3), ci = 32 * hc + 8 * (lane >> 4) + j;
-            out[((((size_t)cg * 18 + st) * 2 + ct) * 64 + lane) * 8 + j] = cvt16(wf[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx], dtype);
-          }
-  return out;
-}
-
 inline std::vector<float> naive_layout(const std::vector<float>& wf, int cout, int cin, int k) {
   std::vector<float> out((size_t)cout * cin * k * k);
   for (int co = 0; co < cout; ++co)

@@ -223,32 +223,6 @@ def test_register_weight_layer2_kernel_against_conv_w4(state_dict, B, dtype, str
     assert _rel(outs[0][1], outs[1][1]) <= tol / 2
 
 
-@pytest.mark.parametrize("B,dtype,streams", [(3, "f16", 1), (40, "bf16", 1), (150, "f16", 2)])
-def test_register_weight_layer1_kernel_against_conv_r4(state_dict, B, dtype, streams):
-    """conv_l1r (r05, default for the four layer-1 convolutions on 224 x 224 crops: 8 waves, two per SIMD, all weights in registers, a
-    quarter of the band's pixel tiles per wave in two sub-tiles, conv2 with the residual) against conv_r4 (option l1r = 0): the same K
-    order (half-chunk, tap, channel), accumulators from the bias, residual last -> every stage and the rotation BIT for bit; and inside
-    the emulating oracle's stage tolerance.  B = 150: 1050 bands on 256 workgroups (four or five per workgroup: patch double-buffering)."""
-    torch.manual_seed(23)
-    x = torch.rand(B, 3, 224, 224)
-    tol = 2e-3 if dtype == "f16" else 1e-2
-    n = min(B, 8)
-    emu = O.forward_stages_emulated(state_dict, x[:n], TDT[dtype])
-    outs = []
-    for l1r in (1, 0):
-        e = _engine(state_dict, 224, 224, B, dtype, l1r=l1r, streams=streams)
-        r9, R = _run(e, x)
-        kernels = [k for _, k, _ in e.launch_info(B)]
-        assert sum("conv_l1r_kernel" in k for k in kernels) == (4 if l1r else 0), kernels
-        assert sum("conv_r4_kernel" in k for k in kernels) == (0 if l1r else 4), kernels
-        outs.append([r9, R] + [e.read_stage(s, B).cpu() for s in ("layer1.0", "layer1.1", "layer4.1")])
-        e.close()
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
-    assert _rel(outs[0][3][:n], emu["layer1.1"][:n]) <= tol
-    assert _rel(outs[0][0][:n], emu["r9"][:n]) <= tol
-
-
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
 def test_rotations_vs_fp32_oracle_cfg1(state_dict, golden_cfg1, dtype, rtol, deg):
     """BASELINE cfg1 inputs (16 seeded 224x224 crops) against the committed goldens."""
