@@ -50,6 +50,19 @@ void hh_pack_stem(const float* w, int dtype, uint16_t* dst) {
   memcpy(dst, p.data(), p.size() * 2);
 }
 
+// register-weight fragment images of conv_s2r (64 -> 128, stride 2) and conv_s1r (128 -> 128, K split over wave pairs), r05
+void hh_pack_s2r(const float* w, int dtype, uint16_t* dst) {
+  std::vector<float> wf(w, w + (size_t)128 * 64 * 9);
+  std::vector<uint16_t> p = flope_host::pack_s2r(wf, 128, 64, dtype);
+  memcpy(dst, p.data(), p.size() * 2);
+}
+
+void hh_pack_s1r(const float* w, int dtype, uint16_t* dst) {
+  std::vector<float> wf(w, w + (size_t)128 * 128 * 9);
+  std::vector<uint16_t> p = flope_host::pack_s1r(wf, 128, dtype);
+  memcpy(dst, p.data(), p.size() * 2);
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -223,6 +223,42 @@ def test_pack_stem_layout(harness):
             np.testing.assert_array_equal(logical, expect)
 
 
+def _mfma_a_fragment(vals, lane):
+    """(row i, k slot) of an A fragment as the MFMA reads it: lane -> matrix row lane & 15, k = 8 (lane >> 4) .. + 7."""
+    return lane & 15, 8 * (lane >> 4)
+
+
+def test_pack_s2r_and_s1r_fragment_images(harness):
+    """conv_s2r / conv_s1r keep their weights in registers; a wave-load is one contiguous KiB [lane][8] in A-fragment order.  Every
+    weight appears exactly once, and lane (i = lane & 15, g = lane >> 4) of fragment (wave, step = half-chunk * 9 + tap, ct) holds
+    W[32 wave + 8 (i >> 2) + 4 ct + (i & 3)][input channel base + 32 hc + 8 g + j][tap] -- so that MFMA output rows 4 g .. 4 g + 3 of
+    channel tile ct are eight consecutive channels per lane (one 16-byte store per pixel)."""
+    rng = np.random.default_rng(5)
+    w2 = rng.integers(-1000, 1000, (128, 64, 3, 3)).astype(np.float32)
+    out = np.empty(4 * 18 * 2 * 64 * 8, np.uint16)
+    harness.hh_pack_s2r(_f(np.ascontiguousarray(w2)), 1, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    v = torch.from_numpy(out.view(np.int16)).view(torch.float16).float().numpy().reshape(4, 18, 2, 64, 8)
+    assert np.array_equal(np.sort(v.reshape(-1)), np.sort(w2.reshape(-1)))
+    for wave, st, ct, lane in ((0, 0, 0, 0), (3, 17, 1, 63), (2, 9, 0, 37), (1, 4, 1, 18)):
+        i, k0 = _mfma_a_fragment(v, lane)
+        hc, tap = divmod(st, 9)
+        co = 32 * wave + 8 * (i >> 2) + 4 * ct + (i & 3)
+        np.testing.assert_array_equal(v[wave, st, ct, lane], w2[co, 32 * hc + k0:32 * hc + k0 + 8, tap // 3, tap % 3])
+    w1 = rng.integers(-1000, 1000, (128, 128, 3, 3)).astype(np.float32)
+    out = np.empty(4 * 2 * 18 * 2 * 64 * 8, np.uint16)
+    harness.hh_pack_s1r(_f(np.ascontiguousarray(w1)), 1, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    v = torch.from_numpy(out.view(np.int16)).view(torch.float16).float().numpy().reshape(4, 2, 18, 2, 64, 8)
+    assert np.array_equal(np.sort(v.reshape(-1)), np.sort(w1.reshape(-1)))
+    for cg, kh, st, ct, lane in ((0, 0, 0, 0, 0), (3, 1, 17, 1, 63), (2, 0, 9, 0, 37), (1, 1, 4, 1, 18)):
+        i, k0 = _mfma_a_fragment(v, lane)
+        hc, tap = divmod(st, 9)
+        co = 32 * cg + 8 * (i >> 2) + 4 * ct + (i & 3)
+        ci = 64 * kh + 32 * hc + k0
+        np.testing.assert_array_equal(v[cg, kh, st, ct, lane], w1[co, ci:ci + 8, tap // 3, tap % 3])
+    # the two K halves of a pair partition the input channels: kh 0 never sees a channel >= 64
+    np.testing.assert_array_equal(np.sort(v[:, 0].reshape(-1)), np.sort(w1[:, :64].reshape(-1)))
+
+
 # ---- checkpoint inventory -------------------------------------------------------------------------
 def test_state_dict_inventory(state_dict):
     from flope_amd.weights import expected_keys, validate_state_dict
