@@ -31,8 +31,12 @@ __device__ __forceinline__ void glds16(const char* gptr, unsigned lds_addr) {
 }
 #define GLDS16(gptr, lptr) glds16((gptr), (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)(lptr)))
 
-template <typename T, bool RES>
+// FOLD (layer2.0.conv2): the block's 1x1 stride-2 shortcut conv as one more step -- out += W_ds . x(2 r, 2 c) over the 64 channels of the
+// block input x, wave kh taking channels 32 kh .. 32 kh + 31 (one more A fragment pair); its pixel fragments come straight from global
+// memory (16 bytes per lane, issued five steps before the extra step: x is 14 KB per band and there is no LDS left for it).
+template <typename T, bool RES, bool FOLD>
 __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u32x4* __restrict__ wpk) {
+  static_assert(!(RES && FOLD), "the folded shortcut replaces the residual");
   typedef typename Elem<T>::frag frag;
   constexpr int NPT = 7, WO = 28;
   constexpr int PROW_B = 32 * 64;          // image row pitch: 32 pixels (30 used) of 64 bytes
@@ -89,6 +93,15 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
     for (int ct = 0; ct < 2; ++ct) wres[s][ct] = __builtin_bit_cast(frag, wl[(s * 2 + ct) * 64]);
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) b4[ct] = *(const f32x4*)(p.bias + 32 * cg + 8 * g + 4 * ct);
+  frag wds[2];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) wds[ct] = __builtin_bit_cast(frag, ((const u32x4*)p.ds_w)[((cg * 2 + kh) * 2 + ct) * 64 + lane]);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) asm volatile("" : "+v"(wds[ct]));
+  }
+  // shortcut pixel of output (rr, cc) of pixel tile 0: padded x(2 rr + 1, 2 cc + 1), this wave's 32 channels, this lane's 8
+  const int xsoff = FOLD ? ((2 * rr + 1) * p.ds_Wip + 2 * cc + 1) * 128 + kh * 64 + g * 16 : 0;
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
@@ -106,6 +119,7 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
   const char* nsrc = nullptr;
+  const char* xsrc = nullptr;                      // FOLD: the band's rows of the block input (+ this lane's offset)
   size_t opix = 0;
 
   // One SUB-TILE = NP of the band's seven pixel tiles (4, then 3: seven at once need 56 accumulator + 28 fragment registers beside the
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
     const int nbuf = cur ^ 1;
     f32x4 acc[NP][2];
     frag xf[2][NP];
+    frag xs[NP];
     S1R_STAMP(FIRST ? 0 : 5);
     auto xaddr = [&](int s) -> const char* {   // pixel fragments of step s (half-chunk s / 9, tap s % 9), the sub-tile's first pixel tile
       const int hc = s / 9, tap = s - 9 * hc, ky = tap / 3, kx = tap - 3 * ky;
@@ -150,10 +165,17 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
           acc[pt][ct] = Elem<T>::mfma(wres[s][ct], xf[s & 1][pt], s == 0 ? (KH ? zero4 : b4[ct]) : acc[pt][ct]);
         if (s + 1 < NSTEP) xf[(s + 1) & 1][pt] = *(const frag*)(xaddr(s + 1) + pt * 256);
         if (FIRST && s < 3 && pt < 2) S1R_PIECE(nsrc, nbuf, 2 * s + pt);       // the next band's six pieces
+        if (FOLD && s == 12) xs[pt] = *(const frag*)(xsrc + (P0 + pt) * 1024);   // 4 columns = 8 pixels of x = 1024 bytes per pixel tile
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (FIRST && s < 3 && pt < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if ((FIRST && s < 3 && pt < 2) || (FOLD && s == 12)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
+    }
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = Elem<T>::mfma(wds[ct], xs[pt], acc[pt][ct]);
     }
     S1R_STAMP(FIRST ? 1 : 6);
     // the partner's share of the partial sums -> swap area; the residual of the own share comes in meanwhile
@@ -205,6 +227,7 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
     for (; tile < total; tile += G) {
       nsrc = band(tile + G);
       const int img = tile / rgs, rg = tile - img * rgs;
+      if constexpr (FOLD) xsrc = (const char*)p.ds_in + ((size_t)img * p.ds_Hip + 8 * rg) * p.ds_Wip * 128 + xsoff;
       opix = (((size_t)img * p.Hop + 4 * rg + 1) * p.Wop + 1) * p.Cout * 2 + ooff;
       sub(kh_, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
       sub(kh_, std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
@@ -233,9 +256,11 @@ __global__ __launch_bounds__(512, 1) void conv_s1r_kernel(const ConvP p, const u
 
 }  // namespace
 
-// layer shapes this kernel takes: 3x3 stride 1, 128 -> 128 channels, 28-wide map with a multiple of 4 rows, no folded shortcut
+// layer shapes this kernel takes: 3x3 stride 1, 128 -> 128 channels, 28-wide map with a multiple of 4 rows; a folded 1x1 stride-2
+// shortcut over 64 input channels (ds_w: pack_s1r_ds image) instead of a residual
 extern "C" int flope_conv_s1r_ok(const ConvP* p) {
-  return p->stride == 1 && p->ntaps == 9 && p->Cin == 128 && p->Cout == 128 && p->Wo == 28 && (p->Ho & 3) == 0 && !p->ds_in &&
+  if (p->ds_in && !(p->ds_Cin == 64 && p->ds_Hip == 2 * p->Ho + 2 && p->ds_Wip == 2 * p->Wo + 2 && p->ds_w && !p->res)) return 0;
+  return p->stride == 1 && p->ntaps == 9 && p->Cin == 128 && p->Cout == 128 && p->Wo == 28 && (p->Ho & 3) == 0 &&
          p->ksplit <= 1 && p->Wip == p->Wo + 2 && p->Hip == p->Ho + 2;
 }
 
@@ -243,8 +268,8 @@ extern "C" int flope_conv_s1r_lds() { return 2 * 4 * 6 * 32 * 64 + 4 * 14 * 1024
 
 extern "C" int flope_conv_s1r_init() {
   hipError_t e = hipSuccess;
-#define A(T, R) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s1r_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, flope_conv_s1r_lds());
-  A(bf16_t, false) A(bf16_t, true) A(f16_t, false) A(f16_t, true)
+#define A(T, R, F) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s1r_kernel<T, R, F>, hipFuncAttributeMaxDynamicSharedMemorySize, flope_conv_s1r_lds());
+  A(bf16_t, false, false) A(bf16_t, true, false) A(bf16_t, false, true) A(f16_t, false, false) A(f16_t, true, false) A(f16_t, false, true)
 #undef A
   return (int)e;
 }
@@ -257,8 +282,9 @@ extern "C" int flope_conv_s1r_launch(const ConvP* p, const void* w, int dtype, i
   if (grid < 1) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)flope_conv_s1r_lds();
   hipStream_t st = (hipStream_t)stream;
-#define GO(T) do { if (p->res) hipLaunchKernelGGL((conv_s1r_kernel<T, true>), dim3(grid), dim3(512), lds, st, *p, (const u32x4*)w);  \
-                   else hipLaunchKernelGGL((conv_s1r_kernel<T, false>), dim3(grid), dim3(512), lds, st, *p, (const u32x4*)w); } while (0)
+#define GO(T) do { if (p->ds_in) hipLaunchKernelGGL((conv_s1r_kernel<T, false, true>), dim3(grid), dim3(512), lds, st, *p, (const u32x4*)w);  \
+                   else if (p->res) hipLaunchKernelGGL((conv_s1r_kernel<T, true, false>), dim3(grid), dim3(512), lds, st, *p, (const u32x4*)w);  \
+                   else hipLaunchKernelGGL((conv_s1r_kernel<T, false, false>), dim3(grid), dim3(512), lds, st, *p, (const u32x4*)w); } while (0)
   if (dtype == 0) GO(bf16_t); else GO(f16_t);
 #undef GO
   return (int)hipGetLastError();

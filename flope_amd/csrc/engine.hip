@@ -89,6 +89,7 @@ struct Conv {
   // on that conv2, ds_conv is the index of the downsample and bias_fused = bias + bias of the downsample
   int folded = 0, ds_conv = -1;
   void* w_ds_stag = nullptr;   // downsample conv only: its weights as a conv_stag image
+  void* w_ds_s1r = nullptr;    // the 64 -> 128 downsample conv only: its weights as conv_s1r's extra fragment pair
   float* bias_fused = nullptr; // conv2 only
   // what the LAST forward launched for this conv (run_slice): kernel family as flope_launch_info names it, and the launch's shape
   mutable std::string last_kernel, last_detail;
@@ -531,7 +532,7 @@ extern "C" int flope_destroy(flope_handle e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   for (Buf& b : e->bufs) if (b.ptr) hipFree(b.ptr);
-  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_s2r) hipFree(c.w_s2r); if (c.w_s1r) hipFree(c.w_s1r); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.bias_fused) hipFree(c.bias_fused); }
+  for (Conv& c : e->convs) { if (c.w_packed) hipFree(c.w_packed); if (c.w_stag) hipFree(c.w_stag); if (c.w_s2r) hipFree(c.w_s2r); if (c.w_s1r) hipFree(c.w_s1r); if (c.w_naive) hipFree(c.w_naive); if (c.bias) hipFree(c.bias); if (c.w_ds_stag) hipFree(c.w_ds_stag); if (c.w_ds_s1r) hipFree(c.w_ds_s1r); if (c.bias_fused) hipFree(c.bias_fused); }
   void* singles[] = {e->stem_in, e->stem_q, e->stem_w, e->stem_w2, e->stem_w_naive, e->stem_bias, e->feat, e->hidden, e->W1, e->W1p, e->b1, e->W2, e->b2, e->r9_scratch, e->split_ws};
   for (void* p : singles) if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
@@ -627,6 +628,7 @@ extern "C" int flope_load_weights(flope_handle e, int n, const char* const* name
       if (c.k == 3 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32(wf, c.cout, c.cin, e->dtype), &c.w_stag)) != 0) return rc;
       if (c.k == 3 && c.stride == 1 && c.cin == 128 && c.cout == 128 && (rc = upload(e, pack_s1r(wf, c.cin, e->dtype), &c.w_s1r)) != 0) return rc;
       if (c.k == 3 && c.stride == 2 && c.cin == 64 && c.cout == 128 && (rc = upload(e, pack_s2r(wf, c.cout, c.cin, e->dtype), &c.w_s2r)) != 0) return rc;
+      if (c.k == 1 && c.stride == 2 && c.cin == 64 && c.cout == 128 && (rc = upload(e, pack_s1r_ds(wf, c.cin, e->dtype), &c.w_ds_s1r)) != 0) return rc;
       if (c.k == 1 && c.cout >= 128 && c.cin % 64 == 0 && (rc = upload(e, pack_conv32_1x1(wf, c.cout, c.cin, e->dtype), &c.w_ds_stag)) != 0) return rc;
     }
     host_bias.push_back(bf);
@@ -747,17 +749,21 @@ static int run_slice(flope_engine* e, const void* x_dev, int in_format, int star
       p.w = c.w_stag; p.per_image = 0; p.mtiles = (p.M + sbm - 1) / sbm; p.ntiles = c.cout == 64 ? 1 : c.cout / 128; p.patch_rows_max = c.stag_patch_bytes;
       p.total_tiles = p.mtiles * p.ntiles;
       p.skew = e->opt_skew; p.prio = e->opt_prio;
-      if (e->opt_s1r && c.w_s1r && c.ds_conv < 0 && c.stag == 1 && flope_conv_s1r_ok(&p)) {   // r05: weights in registers, K split over wave pairs (conv_s1r.hip)
-        SMARK();
-        c.last_kernel = "conv_s1r_kernel<4rows x28>"; c.last_detail.clear();
-        if ((e->opt_dbg & 64) && e->split_ws) p.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
-        K_TRY(e, c.name.c_str(), flope_conv_s1r_launch(&p, c.w_s1r, dt, e->num_cus, stream));
-        continue;
-      }
       if (c.ds_conv >= 0) {
         const Conv& cd = e->convs[c.ds_conv];
         p.res = nullptr; p.bias = c.bias_fused;
         p.ds_in = vb[cd.in_buf].ptr; p.ds_w = cd.w_ds_stag; p.ds_Hip = cd.hin + 2; p.ds_Wip = cd.win + 2; p.ds_Cin = cd.cin;
+      }
+      if (e->opt_s1r && c.w_s1r && c.stag == 1 && (c.ds_conv < 0 || e->convs[c.ds_conv].w_ds_s1r)) {   // r05: weights in registers, K split over wave pairs (conv_s1r.hip)
+        ConvP q = p;
+        if (c.ds_conv >= 0) q.ds_w = e->convs[c.ds_conv].w_ds_s1r;
+        if (flope_conv_s1r_ok(&q)) {
+          SMARK();
+          c.last_kernel = "conv_s1r_kernel<4rows x28>"; c.last_detail = c.ds_conv >= 0 ? "[shortcut folded in]" : "";
+          if ((e->opt_dbg & 64) && e->split_ws) q.split_ws = e->split_ws + (size_t)(&c - &e->convs[0]) * (kDbgRegion / 4);
+          K_TRY(e, c.name.c_str(), flope_conv_s1r_launch(&q, c.w_s1r, dt, e->num_cus, stream));
+          continue;
+        }
       }
       if (c.stag == 2) { p.per_image = 2; p.nseg = c.nseg; p.tiles_per_image = c.hout / 8 * c.nseg; p.mtiles = batch * p.tiles_per_image; p.total_tiles = p.mtiles; }
       // persistent grid: one workgroup per CU (a multiple of ntiles so a workgroup keeps its channel tile); the
@@ -1105,7 +1111,7 @@ extern "C" int flope_launch_info(flope_handle e, int idx, int batch, char* name,
     char k[96];
     if (f32) snprintf(k, sizeof k, "naive_conv_kernel");
     else if (c.stag == 3) snprintf(k, sizeof k, "conv_gstag_kernel<256x128,s2>");
-    else if (e->opt_s1r && c.w_s1r && c.ds_conv < 0 && c.stag == 1 && c.wout == 28 && c.hout % 4 == 0) snprintf(k, sizeof k, "conv_s1r_kernel<4rows x28>");
+    else if (e->opt_s1r && c.w_s1r && (c.ds_conv < 0 || e->convs[c.ds_conv].w_ds_s1r) && c.stag == 1 && c.wout == 28 && c.hout % 4 == 0) snprintf(k, sizeof k, "conv_s1r_kernel<4rows x28>");
     else if (w4_eligible(e, c)) snprintf(k, sizeof k, "conv_w4_kernel<256x128>");
     else if (c.stag == 2 && e->opt_r4 && c.nseg <= 1 && c.cin == 64 && c.cout == 64 && c.wout == 56 && c.hout % 8 == 0) snprintf(k, sizeof k, "conv_r4_kernel<8rows x56>");
     else if (c.stag) snprintf(k, sizeof k, c.stag == 2 ? "conv_stag_kernel<8rows x64>" : (c.cout == 64 ? "conv_stag_kernel<512x64>" : "conv_stag_kernel<256x128>"));

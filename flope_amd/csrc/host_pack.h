@@ -206,6 +206,21 @@ inline std::vector<uint16_t> pack_s1r(const std::vector<float>& wf, int cin, int
   return out;
 }
 
+// conv_s1r with the folded 1x1 stride-2 shortcut (layer2.0.conv2): one more A fragment pair per wave,
+// [4 cg][2 kh][2 ct][64 lanes][8]  <-  W_ds[32 cg + 8 (i >> 2) + 4 ct + (i & 3)][ci = 32 kh + 8 (lane >> 4) + j]   (64 input channels)
+inline std::vector<uint16_t> pack_s1r_ds(const std::vector<float>& wf, int cin, int dtype) {
+  std::vector<uint16_t> out((size_t)4 * 2 * 2 * 64 * 8);
+  for (int cg = 0; cg < 4; ++cg)
+    for (int kh = 0; kh < 2; ++kh)
+      for (int ct = 0; ct < 2; ++ct)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int i = lane & 15, co = 32 * cg + 8 * (i >> 2) + 4 * ct + (i & 3), ci = 32 * kh + 8 * (lane >> 4) + j;
+            out[((((size_t)cg * 2 + kh) * 2 + ct) * 64 + lane) * 8 + j] = cvt16(wf[(size_t)co * cin + ci], dtype);
+          }
+  return out;
+}
+
 inline std::vector<float> naive_layout(const std::vector<float>& wf, int cout, int cin, int k) {
   std::vector<float> out((size_t)cout * cin * k * k);
   for (int co = 0; co < cout; ++co)

@@ -200,10 +200,11 @@ def test_stride2_patch_kernel_against_the_gathered_tile_kernel(state_dict, B, dt
 
 @pytest.mark.parametrize("B,dtype,streams", [(3, "f16", 1), (40, "bf16", 1), (150, "f16", 2)])
 def test_register_weight_layer2_kernel_against_conv_w4(state_dict, B, dtype, streams):
-    """conv_s1r (r05, default for layer2.1.conv1 / conv2 on 224 x 224 crops: K split over wave pairs, all weights in registers, partial
-    sums swapped through LDS; conv2 with the residual) against conv_w4 (option s1r = 0): different K order, so equal within
-    accumulation-order rounding; both inside the emulating oracle's stage tolerance.  B = 150: 1050 bands on 256 workgroups
-    (four or five per workgroup: patch double-buffering, swap-slot reuse)."""
+    """conv_s1r (r05, default for layer2.0.conv2 / layer2.1.conv1 / conv2 on 224 x 224 crops: K split over wave pairs, all weights in
+    registers, partial sums swapped through LDS; 2.1.conv2 with the residual, 2.0.conv2 with the block's 1x1 stride-2 shortcut folded in
+    as one more step) against conv_w4 (option s1r = 0): different K order, so equal within accumulation-order rounding; both inside
+    the emulating oracle's stage tolerance.  B = 150: 1050 bands on 256 workgroups (four or five per workgroup: patch
+    double-buffering, swap-slot reuse).  With dsfuse = 0 the shortcut is its own launch and 2.0.conv2 takes it as a residual."""
     torch.manual_seed(19)
     x = torch.rand(B, 3, 224, 224)
     tol = 2e-3 if dtype == "f16" else 1e-2
@@ -214,13 +215,20 @@ def test_register_weight_layer2_kernel_against_conv_w4(state_dict, B, dtype, str
         e = _engine(state_dict, 224, 224, B, dtype, s1r=s1r, streams=streams)
         r9, R = _run(e, x)
         kernels = [k for _, k, _ in e.launch_info(B)]
-        assert sum("conv_s1r_kernel" in k for k in kernels) == (2 if s1r else 0), kernels
-        outs.append((r9, e.read_stage("layer2.1", B).cpu()))
+        assert sum("conv_s1r_kernel" in k for k in kernels) == (3 if s1r else 0), kernels
+        outs.append((r9, e.read_stage("layer2.1", B).cpu(), e.read_stage("layer2.0", B).cpu()))
         e.close()
-    for r9, l2 in outs:
-        assert _rel(l2[:n], emu["layer2.1"][:n]) <= tol
+    for r9, l21, l20 in outs:
+        assert _rel(l20[:n], emu["layer2.0"][:n]) <= tol
+        assert _rel(l21[:n], emu["layer2.1"][:n]) <= tol
         assert _rel(r9[:n], emu["r9"][:n]) <= tol
-    assert _rel(outs[0][1], outs[1][1]) <= tol / 2
+    assert _rel(outs[0][1], outs[1][1]) <= tol / 2 and _rel(outs[0][2], outs[1][2]) <= tol / 2
+    if B == 3:                                             # the un-folded shortcut: 2.0.conv2 = conv_s1r with a residual
+        e = _engine(state_dict, 224, 224, B, dtype, dsfuse=0, streams=streams)
+        r9, _ = _run(e, x)
+        assert sum("conv_s1r_kernel" in k for _, k, _ in e.launch_info(B)) == 3
+        assert _rel(e.read_stage("layer2.0", B).cpu()[:n], emu["layer2.0"][:n]) <= tol and _rel(r9[:n], emu["r9"][:n]) <= tol
+        e.close()
 
 
 @pytest.mark.parametrize("dtype,rtol,deg", [("f16", 1e-3, 0.1), ("bf16", 1e-2, 1.0)])
