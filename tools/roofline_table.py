@@ -14,12 +14,12 @@ FWD = 20.0   # forwards in the kernel-trace run (tools/profile_target.py 20), 4 
 
 
 def fam(k):
-    if "conv_w4" in k: return "conv_w4<256x128> (layers 2-4, 3x3 s1, 4 waves; three of nine carry the folded 1x1 shortcut)", 59.19 + 3.29 / 3
+    if "conv_w4" in k: return "conv_w4<256x128> (layers 3-4, 3x3 s1, 4 waves; two of six carry the folded 1x1 shortcut)", 59.19 + 3.29 / 3
     if "conv_r4" in k: return "conv_r4<8 rows x 56> (layer 1, 4 waves)", 59.19
     if "conv_stag" in k and "Li64E" in k: return "conv_stag<8 rows x 64> (layer 1)", 59.19
     if "conv_stag" in k: return "conv_stag<256x128> (layers 2-4, 3x3 s1; three of nine carry the folded 1x1 shortcut)", 59.19 + 3.29 / 3
     if "conv_gstag" in k: return "conv_gstag<256x128,s2> (3x3 s2, Cin >= 128)", 29.59
-    if "conv_s1r" in k: return "conv_s1r<4 rows x 28> (layer2.1.conv1 / conv2: 3x3 s1, 128 -> 128; K split over wave pairs, weights in registers)", 59.19
+    if "conv_s1r" in k: return "conv_s1r<4 rows x 28> (layer 2, 3x3 s1, 128 -> 128: 2.0.conv2 + folded shortcut, 2.1.conv1, 2.1.conv2; K split over wave pairs, weights in registers)", 60.29
     if "conv_s2r" in k: return "conv_s2r<4 rows x 28> (layer2.0.conv1: 3x3 s2, 64 -> 128; 8 waves, weights in registers)", 29.59
     if "conv_mfma" in k: return "conv_mfma<128x128,gather> (3x3 s2, Cin = 64)", 29.59
     if "stem_pool" in k: return "stem_pool (conv1 7x7 s2 + bn + relu + maxpool)", 60.42
