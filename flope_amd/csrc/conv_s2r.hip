@@ -16,9 +16,10 @@
 //   * a pixel tile is 4 rows x 4 columns and the 16-byte slots of a pixel are XOR-swizzled by (row, column) -- conflict-free
 //     ds_read_b128 for every tap (see the image description in the kernel).
 // The step stream has two waves per SIMD (225 VGPRs), so one wave's reads, DMA pieces and epilogue run under the other's MFMAs:
-// the 18 steps of a tile take 3.9 k cycles against the 4.0 k of their MFMAs alone.  What bounds the launch is the patch stream
-// (110 MB of input for 14 us of MFMAs): a wave waits ~4.5 k cycles per tile for its pieces of the next one
-// (profiles/r05_conv_s2r.txt has the stamps and the four designs that came before this one).
+// the 18 steps of a tile take 4.4 - 4.7 k cycles against the 4.0 k of their MFMAs alone.  What bounds the launch is the patch stream
+// (110 MB of input for 14 us of MFMAs; 171 MB of HBM traffic per launch = 55 - 60 % of the HBM peak): the next tile's pieces must go out
+// in the first steps of a tile -- issued one per step they arrived 5.6 k cycles late
+// (profiles/r05_conv_s2r.txt has the stamps and the five designs that came before this one).
 // K order: half-chunk, tap, channel (conv_mfma's is tap, channel): results equal conv_mfma's within accumulation-order rounding,
 // not bit for bit (tests/test_gpu_parity.py::test_stride2_patch_kernel_against_the_gathered_tile_kernel).
 #include "common.h"
